@@ -1,0 +1,182 @@
+"""ctypes binding of the C ABI in include/falcon_amd.h (falcon_amd/libfalcon_amd.so).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfalcon_amd.so")
+
+NORM_EXACT64, NORM_WRAP32 = 0, 1
+ST_OK, ST_BAD_PK_HEADER, ST_BAD_SIG_HEADER, ST_BAD_ENCODING, ST_NORM_TOO_LARGE = range(5)
+OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE = 1, 2, 3, 4
+
+# every symbol include/falcon_amd.h declares
+EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile", "fa_strerror", "fa_verify_many",
+           "fa_verify_many_dev", "fa_verify_mixed", "fa_polymul_many", "fa_polymul_many_dev", "fa_pkey_len",
+           "fa_sig_len"]
+
+
+class FaDebug(ctypes.Structure):
+    _fields_ = [("c", ctypes.c_void_p), ("s2", ctypes.c_void_p), ("s1", ctypes.c_void_p),
+                ("norm_exact", ctypes.c_void_p), ("norm_wrap32", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+class FaProfile(ctypes.Structure):
+    _fields_ = [("ms_decode", ctypes.c_double), ("ms_hash", ctypes.c_double), ("ms_verify", ctypes.c_double),
+                ("ms_polymul", ctypes.c_double), ("launches_decode", ctypes.c_uint32),
+                ("launches_hash", ctypes.c_uint32), ("launches_verify", ctypes.c_uint32),
+                ("launches_polymul", ctypes.c_uint32), ("retried_items", ctypes.c_uint32)]
+
+
+class FalconAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libfalcon_amd.so; raises FalconAmdError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FalconAmdError(f"{LIB_PATH} not found: build it with falcon_amd/csrc/build.sh "
+                             "(__graft_entry__.build()); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_size_t
+    lib.fa_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.fa_ctx_destroy.argtypes = [vp]
+    lib.fa_ctx_destroy.restype = None
+    lib.fa_set_option.argtypes = [vp, i32, ctypes.c_int64]
+    lib.fa_get_profile.argtypes = [vp, ctypes.POINTER(FaProfile)]
+    lib.fa_strerror.argtypes = [i32]
+    lib.fa_strerror.restype = ctypes.c_char_p
+    lib.fa_verify_many.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug)]
+    lib.fa_verify_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug), vp]
+    lib.fa_verify_mixed.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.fa_polymul_many.argtypes = [vp, i32, sz, vp, vp, vp]
+    lib.fa_polymul_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_pkey_len.argtypes = [i32]
+    lib.fa_pkey_len.restype = sz
+    lib.fa_sig_len.argtypes = [i32]
+    lib.fa_sig_len.restype = sz
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().fa_strerror(rc).decode()
+        raise FalconAmdError(f"{what} failed: {msg} (code {rc})")
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Context:
+    """One GPU's verifier context (fa_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib.fa_ctx_create(device, ctypes.byref(h)), "fa_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.fa_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt, value):
+        _check(self.lib.fa_set_option(self.handle, opt, value), "fa_set_option")
+
+    def get_profile(self):
+        p = FaProfile()
+        _check(self.lib.fa_get_profile(self.handle, ctypes.byref(p)), "fa_get_profile")
+        return {k: getattr(p, k) for k, _ in FaProfile._fields_}
+
+    # ---- host-buffer entry points (numpy arrays) ----
+    def verify_many(self, logn, pk, msg, sig, msg_off=None, norm_policy=NORM_EXACT64, debug=False):
+        """pk (count, pklen) u8, sig (count, siglen) u8; msg (count, mlen) u8, or flat bytes with
+        msg_off (count+1) u64. Returns accept (count,) u8 and, with debug=True, a dict of intermediates."""
+        n = 1 << logn
+        pk = np.ascontiguousarray(pk, np.uint8)
+        sig = np.ascontiguousarray(sig, np.uint8)
+        msg = np.ascontiguousarray(msg, np.uint8)
+        count = pk.shape[0]
+        if pk.shape != (count, self.lib.fa_pkey_len(logn)) or sig.shape != (count, self.lib.fa_sig_len(logn)):
+            raise ValueError("pk/sig shape does not match logn")
+        if msg_off is None:
+            if msg.ndim != 2 or msg.shape[0] != count:
+                raise ValueError("msg must be (count, mlen) when msg_off is None")
+            mlen, off = msg.shape[1], None
+        else:
+            off = np.ascontiguousarray(msg_off, np.uint64)
+            if off.shape != (count + 1,):
+                raise ValueError("msg_off must hold count+1 offsets")
+            mlen = 0
+        accept = np.zeros(count, np.uint8)
+        dbg = None
+        out = None
+        if debug:
+            out = {"c": np.zeros((count, n), np.uint16), "s2": np.zeros((count, n), np.int16),
+                   "s1": np.zeros((count, n), np.int16), "norm_exact": np.zeros(count, np.uint64),
+                   "norm_wrap32": np.zeros(count, np.uint32), "status": np.zeros(count, np.uint8)}
+            dbg = FaDebug(*[_ptr(out[k]) for k, _ in FaDebug._fields_])
+        mp = _ptr(msg) if msg.size else (None if off is None and mlen == 0 else _ptr(np.zeros(8, np.uint8)))
+        rc = self.lib.fa_verify_many(self.handle, logn, count, _ptr(pk), mp, _ptr(off), mlen, _ptr(sig), norm_policy,
+                                     _ptr(accept), ctypes.byref(dbg) if dbg is not None else None)
+        _check(rc, "fa_verify_many")
+        return (accept, out) if debug else accept
+
+    def verify_mixed(self, logn, pk, pk_off, msg, msg_off, sig, sig_off, norm_policy=NORM_EXACT64):
+        logn = np.ascontiguousarray(logn, np.uint8)
+        count = logn.shape[0]
+        arrs = [np.ascontiguousarray(pk, np.uint8), np.ascontiguousarray(pk_off, np.uint64),
+                np.ascontiguousarray(msg, np.uint8), np.ascontiguousarray(msg_off, np.uint64),
+                np.ascontiguousarray(sig, np.uint8), np.ascontiguousarray(sig_off, np.uint64)]
+        if arrs[2].size == 0:
+            arrs[2] = np.zeros(8, np.uint8)
+        accept = np.zeros(count, np.uint8)
+        rc = self.lib.fa_verify_mixed(self.handle, count, _ptr(logn), *[_ptr(a) for a in arrs], norm_policy,
+                                      _ptr(accept))
+        _check(rc, "fa_verify_mixed")
+        return accept
+
+    def polymul_many(self, logn, a, b):
+        a = np.ascontiguousarray(a, np.uint16)
+        b = np.ascontiguousarray(b, np.uint16)
+        count = a.shape[0]
+        if a.shape != (count, 1 << logn) or b.shape != a.shape:
+            raise ValueError("a/b must be (count, n)")
+        c = np.zeros_like(a)
+        _check(self.lib.fa_polymul_many(self.handle, logn, count, _ptr(a), _ptr(b), _ptr(c)), "fa_polymul_many")
+        return c
+
+    # ---- device-resident entry points (raw device pointers as ints) ----
+    def verify_many_dev(self, logn, count, pk_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr, accept_ptr,
+                        norm_policy=NORM_EXACT64, debug_ptrs=None, stream=0):
+        dbg = None
+        if debug_ptrs is not None:
+            dbg = FaDebug(*[debug_ptrs.get(k) for k, _ in FaDebug._fields_])
+        rc = self.lib.fa_verify_many_dev(self.handle, logn, count, pk_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr,
+                                         norm_policy, accept_ptr, ctypes.byref(dbg) if dbg is not None else None,
+                                         stream or None)
+        _check(rc, "fa_verify_many_dev")
+
+    def polymul_many_dev(self, logn, count, a_ptr, b_ptr, c_ptr, stream=0):
+        _check(self.lib.fa_polymul_many_dev(self.handle, logn, count, a_ptr, b_ptr, c_ptr, stream or None),
+               "fa_polymul_many_dev")

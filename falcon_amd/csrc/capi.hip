@@ -1,0 +1,543 @@
+// capi.hip -- the C ABI declared in include/falcon_amd.h: contexts, workspace, the chunked
+// decode -> hash -> verify pipeline and the host-buffer wrappers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/falcon_amd.h"
+#include "decode_kernel.hpp"
+#include "hash_kernel.hpp"
+#include "verify_kernel.hpp"
+#include "zq.hpp"
+
+using namespace fa;
+
+#define HIP_TRY(expr)                      \
+  do {                                     \
+    const hipError_t e_ = (expr);          \
+    if (e_ != hipSuccess) return (int)e_;  \
+  } while (0)
+
+namespace {
+
+// ---- twiddle tables (host, plain % arithmetic), indexed like ntt.hpp:62-83 ----
+uint32_t powmod(uint32_t b, uint32_t e)
+{
+  uint32_t r = 1;
+  for (b %= Q; e; e >>= 1, b = b * b % Q)
+    if (e & 1) r = r * b % Q;
+  return r;
+}
+uint32_t bitrev(uint32_t v, int bits)
+{
+  uint32_t r = 0;
+  for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+Tw make_tw(uint32_t w) { return Tw{ w, (uint32_t)(((uint64_t)w << 24) / Q) }; }
+
+struct Tables {
+  std::vector<Tw> fwd, inv;
+  NttConsts nc;
+};
+Tables make_tables(int logn)
+{
+  const uint32_t n = 1u << logn, zeta = logn == 9 ? 49u : 7u;  // ntt.hpp:18,23
+  Tables t;
+  t.fwd.resize(n);
+  t.inv.resize(n);
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t w = powmod(zeta, bitrev(k, logn));
+    t.fwd[k] = make_tw(w);
+    t.inv[k] = make_tw(powmod(w, Q - 2));
+  }
+  const uint32_t ninv = powmod(n, Q - 2);  // ntt.hpp:25-29
+  t.nc.ninv = make_tw(ninv);
+  t.nc.inv_last = make_tw(t.inv[1].w * ninv % Q);
+  return t;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return 0;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return 0;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+  int kind;  // 0 decode, 1 hash, 2 verify, 3 polymul
+};
+
+}  // namespace
+
+struct fa_ctx {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t stream = nullptr;  // private stream for the host-buffer entry points
+  Tw* d_tw[2] = { nullptr, nullptr };
+  Tw* d_itw[2] = { nullptr, nullptr };
+  NttConsts nc[2];
+  uint32_t chunk = 65536;
+  uint32_t hash_blocks[2] = { 9, 17 };
+  bool profile = false;
+  // pipeline workspace (per chunk)
+  DevBuf hraw, s2, sqn, st2, retry_count, retry_list;
+  // staging for the host-buffer entry points
+  DevBuf h_pk, h_sig, h_msg, h_off, h_accept, h_dbg[6], h_a, h_b, h_c;
+  std::vector<EventPair> events;
+  uint32_t retried = 0;
+};
+
+namespace {
+
+struct Guard {  // set the context's device for the duration of a call
+  int prev = -1;
+  int err = 0;
+  explicit Guard(int dev)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = (int)hipSetDevice(dev);
+  }
+  ~Guard()
+  {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename F>
+int timed(fa_ctx* ctx, hipStream_t s, int kind, F&& launch)
+{
+  if (!ctx->profile) {
+    launch();
+    return (int)hipGetLastError();
+  }
+  EventPair ev{ nullptr, nullptr, kind };
+  HIP_TRY(hipEventCreate(&ev.a));
+  HIP_TRY(hipEventCreate(&ev.b));
+  HIP_TRY(hipEventRecord(ev.a, s));
+  launch();
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.b, s));
+  ctx->events.push_back(ev);
+  return 0;
+}
+
+bool aligned4(const void* p) { return ((uintptr_t)p & 3u) == 0; }
+
+// One pass of the three kernels over `slots` items. idx == nullptr: slot s is item s of the arrays
+// given (already offset to the chunk); else item idx[s] of the whole arrays.
+template <int LOGN>
+int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, const uint8_t* pk, const uint8_t* msg,
+             const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, uint32_t nblk, int policy, uint8_t* accept,
+             const DebugOut& dbg, bool debug, uint32_t item_base)
+{
+  using G = Geo<LOGN>;
+  constexpr int T = LOGN - 9;
+  constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  if (slots == 0) return 0;
+  int rc = ctx->hraw.reserve((size_t)slots * nblk * 136);
+  if (rc) return rc;
+  if ((rc = ctx->s2.reserve((size_t)slots * G::N * 2))) return rc;
+  if ((rc = ctx->sqn.reserve((size_t)slots * 4))) return rc;
+  if ((rc = ctx->st2.reserve((size_t)slots))) return rc;
+
+  uint16_t* d_s2 = (uint16_t*)ctx->s2.p;
+  uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
+  uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
+  uint64_t* d_hraw = (uint64_t*)ctx->hraw.p;
+
+  rc = timed(ctx, s, 0, [&] {
+    hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
+                       slots, d_s2, d_sqn, d_st2);
+  });
+  if (rc) return rc;
+  rc = timed(ctx, s, 1, [&] {
+    hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, sig, SIGLEN, msg,
+                       msg_off, mlen, idx, slots, nblk, d_hraw);
+  });
+  if (rc) return rc;
+
+  VerifyArgs<LOGN> A;
+  A.pk = pk;
+  A.hraw = d_hraw;
+  A.s2 = d_s2;
+  A.sqn = d_sqn;
+  A.st2 = d_st2;
+  A.idx = idx;
+  A.tw = ctx->d_tw[T];
+  A.itw = ctx->d_itw[T];
+  A.nc = ctx->nc[T];
+  A.count = slots;
+  A.nblk = nblk;
+  A.wrap32 = policy == FA_NORM_WRAP32;
+  A.accept = accept;
+  A.retry_count = (uint32_t*)ctx->retry_count.p;
+  A.retry_list = (uint32_t*)ctx->retry_list.p;
+  A.item_base = item_base;
+  A.dbg = dbg;
+  const uint32_t want = (slots + VERIFY_WAVES - 1) / VERIFY_WAVES;
+  const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * 8u);
+  rc = timed(ctx, s, 2, [&] {
+    if (debug)
+      hipLaunchKernelGGL((verify_kernel<LOGN, true>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+    else
+      hipLaunchKernelGGL((verify_kernel<LOGN, false>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+  });
+  return rc;
+}
+
+template <int LOGN>
+int verify_dev(fa_ctx* ctx, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+               const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+{
+  using G = Geo<LOGN>;
+  constexpr int T = LOGN - 9;
+  constexpr size_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  DebugOut dbg{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  bool debug = false;
+  if (dbgp) {
+    dbg = DebugOut{ dbgp->c, dbgp->s2, dbgp->s1, (unsigned long long*)dbgp->norm_exact, dbgp->norm_wrap32, dbgp->status };
+    debug = dbg.c || dbg.s2 || dbg.s1 || dbg.norm_exact || dbg.norm_wrap32 || dbg.status;
+  }
+  int rc;
+  if ((rc = ctx->retry_count.reserve(4))) return rc;
+  if ((rc = ctx->retry_list.reserve(std::max<size_t>(count, 1) * 4))) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->retry_count.p, 0, 4, s));
+
+  for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
+    const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
+    DebugOut d = dbg;
+    if (d.c) d.c += c0 * G::N;
+    if (d.s2) d.s2 += c0 * G::N;
+    if (d.s1) d.s1 += c0 * G::N;
+    if (d.norm_exact) d.norm_exact += c0;
+    if (d.norm_wrap32) d.norm_wrap32 += c0;
+    if (d.status) d.status += c0;
+    rc = run_pass<LOGN>(ctx, s, slots, nullptr, pk + c0 * G::PKLEN, msg_off ? msg : msg + c0 * mlen,
+                        msg_off ? msg_off + c0 : nullptr, mlen, sig + c0 * SIGLEN, ctx->hash_blocks[T], policy,
+                        accept + c0, d, debug, (uint32_t)c0);
+    if (rc) return rc;
+  }
+
+  // Items whose rejection sampling ran out of squeezed blocks (probability ~1e-25 / ~1e-13 per item
+  // at the default block counts) are re-hashed with twice as many blocks until none is left.
+  uint32_t nblk = ctx->hash_blocks[T];
+  for (;;) {
+    uint32_t pending = 0;
+    HIP_TRY(hipMemcpyAsync(&pending, ctx->retry_count.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (pending == 0) break;
+    ctx->retried += pending;
+    nblk *= 2;
+    DevBuf list;  // this round's list; the kernels refill ctx->retry_list
+    if ((rc = list.reserve((size_t)pending * 4))) return rc;
+    rc = (int)hipMemcpyAsync(list.p, ctx->retry_list.p, (size_t)pending * 4, hipMemcpyDeviceToDevice, s);
+    if (!rc) rc = (int)hipMemsetAsync(ctx->retry_count.p, 0, 4, s);
+    for (uint32_t r0 = 0; !rc && r0 < pending; r0 += ctx->chunk) {
+      const uint32_t slots = std::min<uint32_t>(ctx->chunk, pending - r0);
+      rc = run_pass<LOGN>(ctx, s, slots, (const uint32_t*)list.p + r0, pk, msg, msg_off, mlen, sig, nblk, policy, accept,
+                          dbg, debug, 0u);
+    }
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    list.release();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+template <int LOGN>
+int polymul_dev(fa_ctx* ctx, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c, hipStream_t s)
+{
+  constexpr int T = LOGN - 9;
+  constexpr size_t MAXP = 1u << 30;  // the kernel indexes polynomials with 32 bits
+  for (size_t p0 = 0; p0 < count; p0 += MAXP) {
+    const uint32_t n = (uint32_t)std::min(MAXP, count - p0);
+    const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+    const size_t o = p0 << LOGN;
+    const int rc = timed(ctx, s, 3, [&] {
+      hipLaunchKernelGGL(polymul_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, a + o, b + o, c + o, n, ctx->d_tw[T],
+                         ctx->d_itw[T], ctx->nc[T]);
+    });
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fa_pkey_len(int logn) { return logn == 9 ? 897 : logn == 10 ? 1793 : 0; }
+size_t fa_sig_len(int logn) { return logn == 9 ? 666 : logn == 10 ? 1280 : 0; }
+
+const char* fa_strerror(int code)
+{
+  switch (code) {
+    case 0: return "ok";
+    case FA_E_ARG: return "invalid argument";
+    case FA_E_LOGN: return "logn must be 9 (Falcon-512) or 10 (Falcon-1024)";
+    case FA_E_ALIGN: return "device arrays must be 4-byte aligned";
+    case FA_E_INTERNAL: return "internal error";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int fa_ctx_create(int device, fa_ctx** out)
+{
+  if (!out) return FA_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return FA_E_ARG;
+  Guard g(device);
+  if (g.err) return g.err;
+  fa_ctx* ctx = new (std::nothrow) fa_ctx;
+  if (!ctx) return FA_E_INTERNAL;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  int rc = (int)hipGetDeviceProperties(&prop, device);
+  if (!rc) {
+    ctx->num_cu = prop.multiProcessorCount;
+    rc = (int)hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  }
+  for (int t = 0; t < 2 && !rc; t++) {
+    const Tables tb = make_tables(9 + t);
+    const size_t bytes = tb.fwd.size() * sizeof(Tw);
+    ctx->nc[t] = tb.nc;
+    rc = (int)hipMalloc((void**)&ctx->d_tw[t], bytes);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_itw[t], bytes);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_tw[t], tb.fwd.data(), bytes, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_itw[t], tb.inv.data(), bytes, hipMemcpyHostToDevice);
+  }
+  if (rc) {
+    fa_ctx_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void fa_ctx_destroy(fa_ctx* ctx)
+{
+  if (!ctx) return;
+  Guard g(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (int t = 0; t < 2; t++) {
+    if (ctx->d_tw[t]) (void)hipFree(ctx->d_tw[t]);
+    if (ctx->d_itw[t]) (void)hipFree(ctx->d_itw[t]);
+  }
+  DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->h_pk,
+                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_accept, &ctx->h_a, &ctx->h_b, &ctx->h_c };
+  for (DevBuf* b : bufs) b->release();
+  for (DevBuf& b : ctx->h_dbg) b.release();
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int fa_set_option(fa_ctx* ctx, int option, int64_t value)
+{
+  if (!ctx) return FA_E_ARG;
+  switch (option) {
+    case FA_OPT_CHUNK_ITEMS:
+      if (value < 64 || value > (1 << 24)) return FA_E_ARG;
+      ctx->chunk = (uint32_t)value;
+      return 0;
+    case FA_OPT_HASH_BLOCKS_512:
+    case FA_OPT_HASH_BLOCKS_1024:
+      if (value < 1 || value > 64) return FA_E_ARG;
+      ctx->hash_blocks[option - FA_OPT_HASH_BLOCKS_512] = (uint32_t)value;
+      return 0;
+    case FA_OPT_PROFILE:
+      ctx->profile = value != 0;
+      return 0;
+    default:
+      return FA_E_ARG;
+  }
+}
+
+int fa_get_profile(fa_ctx* ctx, fa_profile* out)
+{
+  if (!ctx || !out) return FA_E_ARG;
+  Guard g(ctx->device);
+  std::memset(out, 0, sizeof(*out));
+  for (auto& e : ctx->events) {
+    HIP_TRY(hipEventSynchronize(e.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+    double* acc[] = { &out->ms_decode, &out->ms_hash, &out->ms_verify, &out->ms_polymul };
+    uint32_t* cnt[] = { &out->launches_decode, &out->launches_hash, &out->launches_verify, &out->launches_polymul };
+    *acc[e.kind] += ms;
+    *cnt[e.kind] += 1;
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  ctx->events.clear();
+  out->retried_items = ctx->retried;
+  ctx->retried = 0;
+  return 0;
+}
+
+int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
+                       const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept,
+                       const fa_debug* dbg, void* stream)
+{
+  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!pk || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  if (count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (!aligned4(pk) || !aligned4(sig) || !aligned4(msg) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  return logn == 9 ? verify_dev<9>(ctx, count, pk, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
+                   : verify_dev<10>(ctx, count, pk, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
+}
+
+int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off,
+                   uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!pk || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);
+  const size_t msg_bytes = msg_off ? (size_t)msg_off[count] : count * (size_t)mlen;
+  hipStream_t s = ctx->stream;
+  int rc;
+  // +8 bytes of slack: the kernels read whole aligned dwords around the last record
+  if ((rc = ctx->h_pk.reserve(count * pklen + 8))) return rc;
+  if ((rc = ctx->h_sig.reserve(count * siglen + 8))) return rc;
+  if ((rc = ctx->h_msg.reserve(msg_bytes + 8))) return rc;
+  if ((rc = ctx->h_accept.reserve(count))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, pk, count * pklen, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_sig.p, sig, count * siglen, hipMemcpyHostToDevice, s));
+  if (msg_bytes) HIP_TRY(hipMemcpyAsync(ctx->h_msg.p, msg, msg_bytes, hipMemcpyHostToDevice, s));
+  const uint64_t* d_off = nullptr;
+  if (msg_off) {
+    if ((rc = ctx->h_off.reserve((count + 1) * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_off.p, msg_off, (count + 1) * 8, hipMemcpyHostToDevice, s));
+    d_off = (const uint64_t*)ctx->h_off.p;
+  }
+  fa_debug d{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  if (dbg) {
+    const size_t sz[6] = { count * n * 2, count * n * 2, count * n * 2, count * 8, count * 4, count };
+    void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
+    void** dev[6] = { (void**)&d.c, (void**)&d.s2, (void**)&d.s1, (void**)&d.norm_exact, (void**)&d.norm_wrap32,
+                      (void**)&d.status };
+    for (int i = 0; i < 6; i++) {
+      if (!host[i]) continue;
+      if ((rc = ctx->h_dbg[i].reserve(sz[i]))) return rc;
+      *dev[i] = ctx->h_dbg[i].p;
+    }
+  }
+  rc = fa_verify_many_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, (const uint8_t*)ctx->h_msg.p, d_off, mlen,
+                          (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(accept, ctx->h_accept.p, count, hipMemcpyDeviceToHost, s));
+  if (dbg) {
+    const size_t sz[6] = { count * n * 2, count * n * 2, count * n * 2, count * 8, count * 4, count };
+    void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
+    for (int i = 0; i < 6; i++)
+      if (host[i]) HIP_TRY(hipMemcpyAsync(host[i], ctx->h_dbg[i].p, sz[i], hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
+                    const uint8_t* msg, const uint64_t* msg_off, const uint8_t* sig, const uint64_t* sig_off,
+                    int norm_policy, uint8_t* accept)
+{
+  if (!ctx) return FA_E_ARG;
+  if (count == 0) return 0;
+  if (!logn || !pk || !pk_off || !msg_off || !sig || !sig_off || !accept) return FA_E_ARG;
+  for (size_t i = 0; i < count; i++)
+    if (logn[i] != 9 && logn[i] != 10) return FA_E_LOGN;
+  for (int ln = 9; ln <= 10; ln++) {  // partition by N on the host, one pass per class
+    const size_t pklen = fa_pkey_len(ln), siglen = fa_sig_len(ln);
+    std::vector<size_t> who;
+    for (size_t i = 0; i < count; i++)
+      if (logn[i] == ln) who.push_back(i);
+    if (who.empty()) continue;
+    std::vector<uint8_t> gpk(who.size() * pklen), gsig(who.size() * siglen), gmsg, gacc(who.size());
+    std::vector<uint64_t> goff(who.size() + 1, 0);
+    for (size_t k = 0; k < who.size(); k++) {
+      const size_t i = who[k];
+      std::memcpy(&gpk[k * pklen], pk + pk_off[i], pklen);
+      std::memcpy(&gsig[k * siglen], sig + sig_off[i], siglen);
+      const size_t ml = (size_t)(msg_off[i + 1] - msg_off[i]);
+      if (ml) gmsg.insert(gmsg.end(), msg + msg_off[i], msg + msg_off[i] + ml);
+      goff[k + 1] = gmsg.size();
+    }
+    if (gmsg.empty()) gmsg.push_back(0);
+    const int rc = fa_verify_many(ctx, ln, who.size(), gpk.data(), gmsg.data(), goff.data(), 0, gsig.data(), norm_policy,
+                                  gacc.data(), nullptr);
+    if (rc) return rc;
+    for (size_t k = 0; k < who.size(); k++) accept[who[k]] = gacc[k];
+  }
+  return 0;
+}
+
+int fa_polymul_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c,
+                        void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!a || !b || !c) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  return logn == 9 ? polymul_dev<9>(ctx, count, a, b, c, (hipStream_t)stream)
+                   : polymul_dev<10>(ctx, count, a, b, c, (hipStream_t)stream);
+}
+
+int fa_polymul_many(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!a || !b || !c) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t bytes = (count << logn) * 2;
+  int rc;
+  if ((rc = ctx->h_a.reserve(bytes))) return rc;
+  if ((rc = ctx->h_b.reserve(bytes))) return rc;
+  if ((rc = ctx->h_c.reserve(bytes))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_a.p, a, bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_b.p, b, bytes, hipMemcpyHostToDevice, s));
+  rc = fa_polymul_many_dev(ctx, logn, count, (const uint16_t*)ctx->h_a.p, (const uint16_t*)ctx->h_b.p,
+                           (uint16_t*)ctx->h_c.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c, ctx->h_c.p, bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

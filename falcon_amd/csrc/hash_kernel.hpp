@@ -1,0 +1,201 @@
+// hash_kernel.hpp -- SHAKE256 squeeze blocks for hash_to_point, one Keccak sponge per lane.
+//
+// Replaces the sponge half of hashing::hash_to_point (hashing.hpp:30-39, sha3 submodule):
+// absorb salt || msg, pad, then squeeze `nblk` 136-byte blocks per item. The rejection
+// sampling half (hashing.hpp:41-48) runs in the verify kernel, which reads the blocks this
+// kernel leaves in HBM. One lane owns one sponge: 25 x 64-bit lanes = 50 VGPRs, rotations by
+// v_alignbit_b32, theta/chi by the gfx950 three-input v_bitop3_b32 (emitted by hipcc from the
+// boolean expressions below), so a round is about 180 VALU instructions.
+//
+// HBM layout: hraw[slot][nblk][17] little-endian u64 words (row stride nblk*136 bytes). Lanes
+// stage each block in LDS and the wave writes it out as contiguous 136-byte runs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+__constant__ uint32_t KECCAK_RC_LO[24] = {
+  0x00000001u, 0x00008082u, 0x0000808au, 0x80008000u, 0x0000808bu, 0x80000001u, 0x80008081u, 0x00008009u,
+  0x0000008au, 0x00000088u, 0x80008009u, 0x8000000au, 0x8000808bu, 0x0000008bu, 0x00008089u, 0x00008003u,
+  0x00008002u, 0x00000080u, 0x0000800au, 0x8000000au, 0x80008081u, 0x00008080u, 0x80000001u, 0x80008008u };
+__constant__ uint32_t KECCAK_RC_HI[24] = {
+  0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u,
+  0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x80000000u,
+  0x80000000u, 0x80000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x00000000u, 0x80000000u };
+
+struct u64s {  // a 64-bit Keccak lane as two VGPRs
+  uint32_t lo, hi;
+};
+
+template <int R>
+__device__ __forceinline__ u64s rotl64(u64s v)
+{
+  if constexpr (R == 0) {
+    return v;
+  } else if constexpr (R == 32) {
+    return u64s{ v.hi, v.lo };
+  } else if constexpr (R < 32) {
+    return u64s{ __builtin_amdgcn_alignbit(v.lo, v.hi, 32 - R), __builtin_amdgcn_alignbit(v.hi, v.lo, 32 - R) };
+  } else {
+    return u64s{ __builtin_amdgcn_alignbit(v.hi, v.lo, 64 - R), __builtin_amdgcn_alignbit(v.lo, v.hi, 64 - R) };
+  }
+}
+
+__device__ __forceinline__ u64s xor3(u64s a, u64s b, u64s c) { return u64s{ a.lo ^ b.lo ^ c.lo, a.hi ^ b.hi ^ c.hi }; }
+__device__ __forceinline__ u64s chi(u64s a, u64s b, u64s c) { return u64s{ a.lo ^ (~b.lo & c.lo), a.hi ^ (~b.hi & c.hi) }; }
+
+// One Keccak-f[1600] round on a[x + 5y].
+__device__ __forceinline__ void keccak_round(u64s (&a)[25], uint32_t rc_lo, uint32_t rc_hi)
+{
+  u64s c[5], r[5], b[25];
+#pragma unroll
+  for (int x = 0; x < 5; x++) c[x] = xor3(xor3(a[x], a[x + 5], a[x + 10]), a[x + 15], a[x + 20]);
+#pragma unroll
+  for (int x = 0; x < 5; x++) r[x] = rotl64<1>(c[x]);
+  // theta: a[x,y] ^= c[x-1] ^ rot(c[x+1], 1)
+#pragma unroll
+  for (int i = 0; i < 25; i++) a[i] = xor3(a[i], c[(i % 5 + 4) % 5], r[(i % 5 + 1) % 5]);
+  // rho + pi: b[y, 2x+3y] = rot(a[x,y], rho[x,y])
+  b[0] = a[0];
+  b[10] = rotl64<1>(a[1]);
+  b[20] = rotl64<62>(a[2]);
+  b[5] = rotl64<28>(a[3]);
+  b[15] = rotl64<27>(a[4]);
+  b[16] = rotl64<36>(a[5]);
+  b[1] = rotl64<44>(a[6]);
+  b[11] = rotl64<6>(a[7]);
+  b[21] = rotl64<55>(a[8]);
+  b[6] = rotl64<20>(a[9]);
+  b[7] = rotl64<3>(a[10]);
+  b[17] = rotl64<10>(a[11]);
+  b[2] = rotl64<43>(a[12]);
+  b[12] = rotl64<25>(a[13]);
+  b[22] = rotl64<39>(a[14]);
+  b[23] = rotl64<41>(a[15]);
+  b[8] = rotl64<45>(a[16]);
+  b[18] = rotl64<15>(a[17]);
+  b[3] = rotl64<21>(a[18]);
+  b[13] = rotl64<8>(a[19]);
+  b[14] = rotl64<18>(a[20]);
+  b[24] = rotl64<2>(a[21]);
+  b[9] = rotl64<61>(a[22]);
+  b[19] = rotl64<56>(a[23]);
+  b[4] = rotl64<14>(a[24]);
+#pragma unroll
+  for (int y = 0; y < 25; y += 5)
+#pragma unroll
+    for (int x = 0; x < 5; x++) a[y + x] = chi(b[y + x], b[y + (x + 1) % 5], b[y + (x + 2) % 5]);
+  a[0].lo ^= rc_lo;
+  a[0].hi ^= rc_hi;
+}
+
+__device__ __forceinline__ void keccak_f1600(u64s (&a)[25])
+{
+#pragma unroll 1
+  for (int round = 0; round < 24; round++) keccak_round(a, KECCAK_RC_LO[round], KECCAK_RC_HI[round]);
+}
+
+// 4 bytes of a byte string at offset `off` (multiple of 4) from p, where p is at byte `al` of
+// the aligned dword array `base`; bytes at or beyond `len` read as 0. Loads only dwords that
+// hold at least one valid byte, so nothing outside the pages of the string is touched.
+__device__ __forceinline__ uint32_t load_bytes4(const uint32_t* base, uint32_t al, int32_t off, int32_t len)
+{
+  const int32_t rem = len - off;  // valid bytes from off
+  if (rem <= 0) return 0u;
+  const uint32_t* d = base + (off >> 2);
+  uint32_t lo = d[0], hi = 0u;
+  if (al != 0 && rem > (int32_t)(4 - al)) hi = d[1];
+  uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, al);
+  if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+  return v;
+}
+
+constexpr int HASH_WG = 256;
+
+// One lane per item. sig rows: salt = bytes 1..40 (decoding.hpp:389). Messages: fixed length
+// mlen at msg + item*mlen when msg_off == nullptr, else msg + msg_off[item] with length
+// msg_off[item+1] - msg_off[item] (may differ per lane: the absorb loop diverges, the squeeze
+// loop does not). idx (nullable) maps output slot -> item.
+__global__ __launch_bounds__(HASH_WG) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
+                                                       const uint8_t* __restrict__ msg,
+                                                       const uint64_t* __restrict__ msg_off, uint32_t mlen,
+                                                       const uint32_t* __restrict__ idx, uint32_t count,
+                                                       uint32_t nblk, uint64_t* __restrict__ hraw)
+{
+  __shared__ uint64_t stage[HASH_WG / 64][64 * 17];
+  const uint32_t slot = blockIdx.x * HASH_WG + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const bool live = slot < count;
+  const uint32_t item = live ? (idx ? idx[slot] : slot) : 0u;
+
+  u64s a[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) a[i] = u64s{ 0u, 0u };
+
+  if (live) {
+    // --- absorb salt || msg || pad, 136 bytes at a time (hashing.hpp:30-33) ---
+    const uint8_t* sp = sig + (size_t)item * siglen + 1;
+    const uint32_t sal = (uint32_t)((uintptr_t)sp & 3u);
+    const uint32_t* sbase = (const uint32_t*)(sp - sal);
+    const uint8_t* mp;
+    int32_t ml;
+    if (msg_off) {
+      mp = msg + msg_off[item];
+      ml = (int32_t)(msg_off[item + 1] - msg_off[item]);
+    } else {
+      mp = msg + (size_t)item * mlen;
+      ml = (int32_t)mlen;
+    }
+    const uint32_t mal = (uint32_t)((uintptr_t)mp & 3u);
+    const uint32_t* mbase = (const uint32_t*)(mp - mal);
+    const int32_t total = 40 + ml;           // bytes before padding
+    const int32_t nabs = total / 136 + 1;    // absorb blocks, the last one holds the padding
+    for (int32_t blk = 0; blk < nabs; blk++) {
+#pragma unroll
+      for (int w = 0; w < 17; w++) {
+        const int32_t off = blk * 136 + w * 8;  // stream offset of this 64-bit word
+        uint32_t lo, hi;
+        if (off < 40) {  // salt: 40 bytes = words 0..4 of block 0
+          lo = load_bytes4(sbase, sal, off, 40);
+          hi = load_bytes4(sbase, sal, off + 4, 40);
+        } else {
+          lo = load_bytes4(mbase, mal, off - 40, ml);
+          hi = load_bytes4(mbase, mal, off - 36, ml);
+        }
+        // SHAKE domain byte 0x1F right after the data, 0x80 on the last byte of the block
+        if (total >= off && total < off + 4) lo |= 0x1Fu << (8 * (total - off));
+        if (total >= off + 4 && total < off + 8) hi |= 0x1Fu << (8 * (total - off - 4));
+        if (w == 16 && blk == nabs - 1) hi ^= 0x80000000u;
+        a[w].lo ^= lo;
+        a[w].hi ^= hi;
+      }
+      if (blk != nabs - 1) keccak_f1600(a);
+    }
+  }
+
+  // --- squeeze nblk blocks (hashing.hpp:36-39); wave-uniform trip count ---
+  uint64_t* st = stage[wave];
+  const uint32_t slot0 = blockIdx.x * HASH_WG + wave * 64u;  // first slot of this wave
+  const size_t row_words = (size_t)nblk * 17u;
+  for (uint32_t b = 0; b < nblk; b++) {
+    keccak_f1600(a);
+#pragma unroll
+    for (int w = 0; w < 17; w++) st[lane * 17 + w] = ((uint64_t)a[w].hi << 32) | a[w].lo;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // 64 rows x 17 words, written as 17 coalesced 512-byte wave stores
+#pragma unroll
+    for (int t = 0; t < 17; t++) {
+      const uint32_t e = t * 64u + lane;
+      const uint32_t row = e / 17u, w = e - row * 17u;
+      if (slot0 + row < count) hraw[(size_t)(slot0 + row) * row_words + (size_t)b * 17u + w] = st[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+}  // namespace fa

@@ -1,0 +1,387 @@
+// verify_kernel.hpp -- one wave64 per polynomial: rejection sampling, public-key unpack,
+// NTT / pointwise / iNTT over Z_q, and the fused norm epilogue.
+//
+// Replaces, for one item per wave:
+//   hashing.hpp:41-48      rejection sampling of the squeezed SHAKE256 blocks (t < 61445, t mod q)
+//   decoding.hpp:18-48     decode_pkey (14-bit little-endian fields, header = log2 n)
+//   ntt.hpp:120-150        forward negacyclic NTT (Cooley-Tukey, natural in, bit-reversed out)
+//   polynomial.hpp:99-110  pointwise product
+//   ntt.hpp:161-200        inverse NTT (Gentleman-Sande) with the 1/N scaling
+//   verification.hpp:53-79 s1 = c - s2*h, centring, squared norm, comparison with beta^2
+// Only the coefficient-domain values c, s2, s1 and the norm are observable, so the transform
+// uses 2 forward + 1 inverse NTT (the reference runs 3 + 1, verification.hpp:47-57) and its
+// own butterfly order; all arithmetic is exact mod q, hence bit-identical results.
+//
+// Data layout inside a wave (n = 64*R coefficients, R = 8 or 16 per lane, LB = log2 R):
+//   phase A  lane = i & 63,                     regs hold index bits [6, logn)   stages on those bits
+//   phase B  lane = (i>>6 << PB) | (i & (2^PB-1)), regs hold bits [PB, 6), PB = 6 - LB
+//   phase C  lane = i >> LB,                    regs hold bits [0, LB)
+// with two transposes through a per-wave LDS buffer in between (padded so that every
+// ds_read_b32 / ds_write_b32 is bank-conflict free). Twiddles (w, floor(w 2^24/q)) sit in an
+// LDS table per workgroup, indexed like the reference's POWERS_OF_zeta table (ntt.hpp:62-83).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "decode_kernel.hpp"
+#include "zq.hpp"
+
+namespace fa {
+
+constexpr int VERIFY_WAVES = 4;  // waves per workgroup
+constexpr int VERIFY_WG = 64 * VERIFY_WAVES;
+
+template <int LOGN>
+struct Geo {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int R = N / 64;       // coefficients per lane
+  static constexpr int LB = LOGN - 6;    // log2 R
+  static constexpr int PB = 6 - LB;      // lowest index bit held in registers during phase B
+  static constexpr int PKLEN = 1 + 14 * N / 8;
+  static constexpr int XBUF = N + 64;    // dwords of the padded transpose buffer
+  static constexpr uint32_t BETA2 = LOGN == 9 ? 34034726u : 70265242u;  // falcon.hpp:245
+};
+
+struct NttConsts {
+  Tw ninv;      // 1/N
+  Tw inv_last;  // (inverse twiddle of the last inverse stage) * 1/N
+};
+
+// element index held by (lane, reg m) in each phase
+template <int LOGN> __device__ __forceinline__ uint32_t idxA(uint32_t lane, int m) { return ((uint32_t)m << 6) | lane; }
+template <int LOGN> __device__ __forceinline__ uint32_t idxB(uint32_t lane, int m)
+{
+  constexpr int PB = Geo<LOGN>::PB;
+  return ((lane >> PB) << 6) | ((uint32_t)m << PB) | (lane & ((1u << PB) - 1u));
+}
+template <int LOGN> __device__ __forceinline__ uint32_t idxC(uint32_t lane, int m) { return (lane << Geo<LOGN>::LB) | (uint32_t)m; }
+
+// padded LDS addresses (dword units) of element i for the two transposes
+template <int LOGN> __device__ __forceinline__ uint32_t padAB(uint32_t i) { return i + (i >> 6) * (64u / Geo<LOGN>::R); }
+template <int LOGN> __device__ __forceinline__ uint32_t padBC(uint32_t i) { return i + (i >> Geo<LOGN>::LB); }
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Cooley-Tukey stages on register bits LBTOP .. LBTOP-NST+1 of x[] (global bits BTOP ..).
+// Twiddle index of the butterfly (m, m | 1<<lb) at global bit b:  (N >> (b+1)) + (i >> (b+1)),
+// i >> (b+1) = (lanepart << (LB-1-lb)) | (m >> (lb+1))   (see the phase layouts above).
+// `since` counts stages since the last full reduction; inputs of a stage are bounded by
+// 256*((q+11) + 2q*since) < 2^24 while since <= 1, and a full reduction follows every second stage.
+template <int LOGN, int NST, int BTOP, int LBTOP>
+__device__ __forceinline__ void ct_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
+                                          int& since)
+{
+  constexpr int R = Geo<LOGN>::R, LB = Geo<LOGN>::LB, N = Geo<LOGN>::N;
+#pragma unroll
+  for (int s = 0; s < NST; s++) {
+    const int b = BTOP - s, lb = LBTOP - s;
+    const Tw* base = tw + (N >> (b + 1)) + (lanepart << (LB - 1 - lb));
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      const Tw t = base[m >> (lb + 1)];
+      const uint32_t v = shoup(x[m | (1 << lb)], t.w, t.wp);  // <= 256(q+48)
+      x[m | (1 << lb)] = x[m] + (2u * Q256 - v);
+      x[m] = x[m] + v;
+    }
+    if (++since == 2) {
+#pragma unroll
+      for (int m = 0; m < R; m++) x[m] = reduce(x[m]);
+      since = 0;
+    }
+  }
+}
+
+// Gentleman-Sande stages on register bits LBBOT .. LBBOT+NST-1 (global bits BBOT ..), inverse
+// twiddles; same index rule as ct_stages. Inputs of a stage are bounded by 256*(q+11)*2^since.
+// LAST: the final stage of the transform also multiplies by 1/N (ntt.hpp:193-199 folded in).
+template <int LOGN, int NST, int BBOT, int LBBOT, bool LAST>
+__device__ __forceinline__ void gs_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
+                                          int& since, const NttConsts& nc)
+{
+  constexpr int R = Geo<LOGN>::R, LB = Geo<LOGN>::LB, N = Geo<LOGN>::N;
+#pragma unroll
+  for (int s = 0; s < NST; s++) {
+    const int b = BBOT + s, lb = LBBOT + s;
+    const bool last = LAST && s == NST - 1;
+    const Tw* base = tw + (N >> (b + 1)) + (lanepart << (LB - 1 - lb));
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      const Tw t = last ? nc.inv_last : base[m >> (lb + 1)];
+      const uint32_t u = x[m] + x[m | (1 << lb)];
+      const uint32_t d = x[m] + (3u * Q256 - x[m | (1 << lb)]);
+      x[m | (1 << lb)] = shoup(d, t.w, t.wp);
+      x[m] = last ? shoup(u, nc.ninv.w, nc.ninv.wp) : u;
+    }
+    if (!last && ++since == 2) {
+#pragma unroll
+      for (int m = 0; m < R; m++) x[m] = reduce(x[m]);
+      since = 0;
+    }
+  }
+}
+
+template <int LOGN, int PHASE_FROM>  // 0: A->B, 1: B->C, 2: C->B, 3: B->A
+__device__ __forceinline__ void transpose(uint32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
+{
+  constexpr int R = Geo<LOGN>::R;
+#pragma unroll
+  for (int m = 0; m < R; m++) {
+    if constexpr (PHASE_FROM == 0) buf[padAB<LOGN>(idxA<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 1) buf[padBC<LOGN>(idxB<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 2) buf[padBC<LOGN>(idxC<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 3) buf[padAB<LOGN>(idxB<LOGN>(lane, m))] = x[m];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int m = 0; m < R; m++) {
+    if constexpr (PHASE_FROM == 0) x[m] = buf[padAB<LOGN>(idxB<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 1) x[m] = buf[padBC<LOGN>(idxC<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 2) x[m] = buf[padBC<LOGN>(idxB<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 3) x[m] = buf[padAB<LOGN>(idxA<LOGN>(lane, m))];
+  }
+  wave_lds_sync();
+}
+
+// x: scaled canonical-ish (< 256*(q+11)) in phase-A layout  ->  NTT in phase-C layout, < 256*(3q+11)
+template <int LOGN>
+__device__ __forceinline__ void ntt_forward(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw,
+                                            uint32_t* __restrict__ buf, uint32_t lane)
+{
+  using G = Geo<LOGN>;
+  int since = 0;
+  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1>(x, tw, 0u, since);
+  transpose<LOGN, 0>(x, buf, lane);
+  ct_stages<LOGN, G::LB, 5, G::LB - 1>(x, tw, lane >> G::PB, since);
+  transpose<LOGN, 1>(x, buf, lane);
+  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1>(x, tw, lane, since);
+}
+
+// x: < 256*(q+11)*... in phase-C layout (bit-reversed order) -> coefficients in phase-A layout,
+// each <= 256*(q+48), already multiplied by 1/N.
+template <int LOGN>
+__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ itw,
+                                            uint32_t* __restrict__ buf, uint32_t lane, const NttConsts& nc)
+{
+  using G = Geo<LOGN>;
+  int since = 0;
+  gs_stages<LOGN, G::PB, 0, 0, false>(x, itw, lane, since, nc);
+  transpose<LOGN, 2>(x, buf, lane);
+  gs_stages<LOGN, G::LB, G::PB, 0, false>(x, itw, lane >> G::PB, since, nc);
+  transpose<LOGN, 3>(x, buf, lane);
+  gs_stages<LOGN, G::LB, 6, 0, true>(x, itw, 0u, since, nc);
+}
+
+struct DebugOut {  // device pointers, any may be null
+  uint16_t* c;
+  int16_t* s2;
+  int16_t* s1;
+  unsigned long long* norm_exact;
+  uint32_t* norm_wrap32;
+  uint8_t* status;
+};
+
+template <int LOGN>
+struct VerifyArgs {
+  const uint8_t* pk;        // [items][PKLEN]
+  const uint64_t* hraw;     // [slots][nblk*17]
+  const uint16_t* s2;       // [slots][N] lifted, natural order (decode_kernel)
+  const uint32_t* sqn;      // [slots]
+  const uint8_t* st2;       // [slots]
+  const uint32_t* idx;      // slot -> item, nullable
+  const Tw* tw;             // forward twiddles [N]
+  const Tw* itw;            // inverse twiddles [N]
+  NttConsts nc;
+  uint32_t count;           // slots
+  uint32_t nblk;
+  uint32_t wrap32;          // norm policy
+  uint32_t item_base;       // added to item in retry_list entries (chunked main pass)
+  uint8_t* accept;          // [items]
+  uint32_t* retry_count;    // items whose hash needs more blocks
+  uint32_t* retry_list;
+  DebugOut dbg;
+};
+
+template <int LOGN, bool DEBUG>
+__global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN> A)
+{
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, R = G::R;
+  __shared__ Tw s_tw[N];
+  __shared__ Tw s_itw[N];
+  __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  __shared__ uint16_t s_c[VERIFY_WAVES][N];
+
+  for (int i = threadIdx.x; i < N; i += VERIFY_WG) {
+    s_tw[i] = A.tw[i];
+    s_itw[i] = A.itw[i];
+  }
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t* buf = s_buf[wave];
+  uint16_t* cbuf = s_c[wave];
+  const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
+
+  for (uint32_t slot = blockIdx.x * VERIFY_WAVES + wave; slot < A.count; slot += nwaves) {
+    const uint32_t item = A.idx ? A.idx[slot] : slot;
+    const uint8_t* pkrow = A.pk + (size_t)item * G::PKLEN;
+    uint8_t status = A.st2[slot];
+    if (pkrow[0] != (uint8_t)LOGN) status = ST_BAD_PK_HEADER;  // falcon.hpp:240-243 comes first
+    if (status != ST_OK) {  // wave-uniform
+      if (lane == 0) {
+        A.accept[item] = 0;
+        if (DEBUG) {
+          if (A.dbg.status) A.dbg.status[item] = status;
+          if (A.dbg.norm_exact) A.dbg.norm_exact[item] = 0ull;
+          if (A.dbg.norm_wrap32) A.dbg.norm_wrap32[item] = 0u;
+        }
+      }
+      if (DEBUG) {
+        for (int m = 0; m < R; m++) {
+          const uint32_t i = idxA<LOGN>(lane, m);
+          if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = 0;
+          if (A.dbg.s2) A.dbg.s2[(size_t)item * N + i] = 0;
+          if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = 0;
+        }
+      }
+      continue;
+    }
+
+    // ---- rejection sampling (hashing.hpp:38-49): 16-bit big-endian draws in stream order ----
+    const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
+    const uint32_t ndw = A.nblk * 34u;  // dwords, two draws each
+    uint32_t have = 0;                  // accepted so far (wave-uniform)
+    for (uint32_t base = 0; base < ndw && have < (uint32_t)N; base += 64u) {
+      const uint32_t d = base + lane;
+      const uint32_t w = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are rejected
+      const uint32_t t0 = ((w & 0xffu) << 8) | ((w >> 8) & 0xffu);
+      const uint32_t t1 = ((w >> 8) & 0xff00u) | (w >> 24);
+      const bool a0 = t0 < 61445u, a1 = t1 < 61445u;
+      const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const uint32_t p0 = have + __popcll(m0 & below) + __popcll(m1 & below);
+      const uint32_t p1 = p0 + (a0 ? 1u : 0u);
+      if (a0 && p0 < (uint32_t)N) cbuf[p0] = (uint16_t)t0;
+      if (a1 && p1 < (uint32_t)N) cbuf[p1] = (uint16_t)t1;
+      have += __popcll(m0) + __popcll(m1);
+    }
+    if (have < (uint32_t)N) {  // vanishingly rare: host re-hashes this item with more blocks
+      if (lane == 0) {
+        const uint32_t at = atomicAdd(A.retry_count, 1u);
+        A.retry_list[at] = A.item_base + item;
+      }
+      continue;
+    }
+    wave_lds_sync();
+
+    // ---- s2 (already lifted to [0,q), verification.hpp:36-39) ----
+    uint32_t x[R], y[R];
+    const uint16_t* s2row = A.s2 + (size_t)slot * N;
+#pragma unroll
+    for (int m = 0; m < R; m++) x[m] = (uint32_t)s2row[idxA<LOGN>(lane, m)] << 8;
+
+    // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45),
+    //      taken mod q (equivalent to the reference's raw values) ----
+    {
+      const uint32_t pal = (uint32_t)((uintptr_t)pkrow & 3u);
+      const uint32_t* pbase = (const uint32_t*)(pkrow - pal);
+      const uint32_t last_dw = (pal + (uint32_t)G::PKLEN - 1u) >> 2;
+#pragma unroll
+      for (int m = 0; m < R; m++) {
+        const uint32_t bit = (pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
+        const uint32_t dw = bit >> 5, sh = bit & 31u;
+        const uint32_t lo = pbase[dw], hi = pbase[min(dw + 1u, last_dw)];
+        const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 0x3fffu;
+        y[m] = csub(v, Q) << 8;
+      }
+    }
+
+    ntt_forward<LOGN>(x, s_tw, buf, lane);
+    ntt_forward<LOGN>(y, s_tw, buf, lane);
+#pragma unroll
+    for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);  // polynomial.hpp:99-110
+    ntt_inverse<LOGN>(x, s_itw, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
+
+    // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
+    uint32_t acc = 0;
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      const uint32_t i = idxA<LOGN>(lane, m);
+      const uint32_t craw = cbuf[i];                        // < 61445
+      const uint32_t r = mod_q_17(craw + 2u * Q - (x[m] >> 8));  // canonical s1
+      const uint32_t mag = r >= Q / 2u ? Q - r : r;          // |centred s1|, verification.hpp:59-68
+      acc += mag * mag;
+      if (DEBUG) {
+        if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
+        if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= Q / 2u ? (int32_t)r - (int32_t)Q : (int32_t)r);
+        if (A.dbg.s2) {
+          const uint32_t v = s2row[i];
+          A.dbg.s2[(size_t)item * N + i] = (int16_t)(v > Q / 2u ? (int32_t)v - (int32_t)Q : (int32_t)v);
+        }
+      }
+    }
+    unsigned long long total = acc;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o, 64);
+    total += A.sqn[slot];
+    const uint32_t wrapped = (uint32_t)total;
+    const bool ok = A.wrap32 ? ((int32_t)wrapped <= (int32_t)G::BETA2) : (total <= (unsigned long long)G::BETA2);
+    if (lane == 0) {
+      A.accept[item] = ok ? 1 : 0;
+      if (DEBUG) {
+        if (A.dbg.status) A.dbg.status[item] = ok ? ST_OK : ST_NORM_TOO_LARGE;
+        if (A.dbg.norm_exact) A.dbg.norm_exact[item] = total;
+        if (A.dbg.norm_wrap32) A.dbg.norm_wrap32[item] = wrapped;
+      }
+    }
+    wave_lds_sync();  // cbuf/buf are reused by the next item
+  }
+}
+
+// ---- batched negacyclic product c = a*b in Z_q[x]/(x^n+1) (BASELINE.json config 2) ----
+// Same transforms as the verify path: ntt, polynomial::mul, intt (tests/test_ntt.cpp:48-57).
+template <int LOGN>
+__global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                            uint16_t* __restrict__ c, uint32_t count,
+                                                            const Tw* __restrict__ tw, const Tw* __restrict__ itw,
+                                                            const NttConsts nc)
+{
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, R = G::R;
+  __shared__ Tw s_tw[N];
+  __shared__ Tw s_itw[N];
+  __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  for (int i = threadIdx.x; i < N; i += VERIFY_WG) {
+    s_tw[i] = tw[i];
+    s_itw[i] = itw[i];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t* buf = s_buf[wave];
+  const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
+  for (uint32_t p = blockIdx.x * VERIFY_WAVES + wave; p < count; p += nwaves) {
+    uint32_t x[R], y[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      const size_t at = (size_t)p * N + idxA<LOGN>(lane, m);
+      x[m] = mod_q_17(a[at]) << 8;  // inputs may be any u16; the reference's ff_t ctor reduces (ff.hpp:69-76)
+      y[m] = mod_q_17(b[at]) << 8;
+    }
+    ntt_forward<LOGN>(x, s_tw, buf, lane);
+    ntt_forward<LOGN>(y, s_tw, buf, lane);
+#pragma unroll
+    for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);
+    ntt_inverse<LOGN>(x, s_itw, buf, lane, nc);
+#pragma unroll
+    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub(csub(x[m] >> 8, Q), Q);
+  }
+}
+
+}  // namespace fa

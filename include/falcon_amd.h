@@ -1,0 +1,115 @@
+/*
+ * falcon_amd.h -- C ABI of the MI355X batched Falcon-512/1024 verifier.
+ *
+ * The reference (itzmeanjan/falcon) is a header-only C++20 template library with no FFI layer;
+ * its boundary for this path is the template API itself. Each entry point below names the
+ * reference interface it stands in for (file:line under /root/reference). Conventions follow
+ * the reference's: the caller owns every buffer, record lengths are implied by N
+ * (utils.hpp:9-17,39-49: pk 897/1793 bytes, sig 666/1280 bytes), nothing is written except the
+ * outputs, and there is no per-item error channel beyond the accept flag (debug path aside).
+ *
+ * Return value of every int function: 0 ok; < 0 invalid argument (FA_E_*); > 0 a hipError_t.
+ * A context belongs to one GPU and is used by one host thread at a time; contexts on
+ * different GPUs are independent (batches shard by item, no collective is involved).
+ */
+#ifndef FALCON_AMD_H
+#define FALCON_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_E_ARG (-1)       /* null pointer / bad size */
+#define FA_E_LOGN (-2)      /* logn is neither 9 nor 10 */
+#define FA_E_ALIGN (-3)     /* a device array is not 4-byte aligned */
+#define FA_E_INTERNAL (-4)
+
+/* Norm policy: verification.hpp:70-79 sums the squared norm in int32_t,
+ * which overflows for most invalid signatures, so the reference's reject flag depends on its
+ * compiler. EXACT64 = what the source means and what a clang++ build returns; WRAP32 = what a
+ * g++ build returns ((int32_t)(norm mod 2^32) <= beta^2). Valid signatures agree under both. */
+#define FA_NORM_EXACT64 0
+#define FA_NORM_WRAP32 1
+
+/* Per-item status on the debug path (precedence as in falcon.hpp:240-243, verification.hpp:31-34). */
+#define FA_ST_OK 0
+#define FA_ST_BAD_PK_HEADER 1
+#define FA_ST_BAD_SIG_HEADER 2
+#define FA_ST_BAD_ENCODING 3
+#define FA_ST_NORM_TOO_LARGE 4
+
+/* Options for fa_set_option. */
+#define FA_OPT_CHUNK_ITEMS 1     /* items per pipeline pass (workspace size), default 65536 */
+#define FA_OPT_HASH_BLOCKS_512 2 /* SHAKE256 blocks squeezed per item up front, default 9 */
+#define FA_OPT_HASH_BLOCKS_1024 3 /* default 17; items needing more are re-hashed with twice as many */
+#define FA_OPT_PROFILE 4         /* 1: record HIP events around every kernel (see fa_get_profile) */
+
+typedef struct fa_ctx fa_ctx;
+
+/* Debug outputs: the intermediates of verification.hpp:20-80. Any pointer may be NULL. Arrays are
+ * [count][N] (c, s2, s1) or [count]. For items that fail before hashing, c/s2/s1 are zero. */
+typedef struct fa_debug {
+  uint16_t* c;          /* hash_to_point output, hashing.hpp:16-50 */
+  int16_t* s2;          /* decompressed signature polynomial, decoding.hpp:267-361 */
+  int16_t* s1;          /* centred c - s2*h, verification.hpp:59-68 */
+  uint64_t* norm_exact; /* sum s2^2 + sum s1^2 */
+  uint32_t* norm_wrap32;/* the same mod 2^32 */
+  uint8_t* status;      /* FA_ST_* */
+} fa_debug;
+
+typedef struct fa_profile {
+  double ms_decode, ms_hash, ms_verify, ms_polymul; /* summed HIP-event time of each kernel */
+  uint32_t launches_decode, launches_hash, launches_verify, launches_polymul;
+  uint32_t retried_items;                            /* items re-hashed with more squeeze blocks */
+} fa_profile;
+
+/* Context per device: twiddle tables, workspace, a private stream. No reference counterpart (the
+ * reference is stateless); the handle only owns device memory. */
+int fa_ctx_create(int device, fa_ctx** out);
+void fa_ctx_destroy(fa_ctx* ctx);
+int fa_set_option(fa_ctx* ctx, int option, int64_t value);
+int fa_get_profile(fa_ctx* ctx, fa_profile* out); /* synchronises; totals since the last call */
+const char* fa_strerror(int code);
+
+/* Batched falcon::verify<N> (falcon.hpp:230-249), host buffers. pk: count*pklen bytes, sig:
+ * count*siglen bytes. Messages: msg_off == NULL -> fixed length mlen at msg + i*mlen; else message i
+ * is msg[msg_off[i] .. msg_off[i+1]) (count+1 offsets) and mlen is ignored. accept[i] = 1/0 exactly
+ * as the reference's bool. Inputs are copied to device storage; callers need not pad them. */
+int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
+                   const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
+                   uint8_t* accept, const fa_debug* dbg);
+
+/* The same with every pointer (including those inside dbg) a device pointer on ctx's GPU; arrays
+ * must be 4-byte aligned. Work is enqueued on `stream` (a hipStream_t, NULL = default stream); the
+ * call synchronises that stream once before returning (it has to learn whether any item needs the
+ * re-hash pass). This is the entry point the throughput figure is measured on. */
+int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
+                       const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
+                       uint8_t* accept, const fa_debug* dbg, void* stream);
+
+/* Mixed Falcon-512 / Falcon-1024 batch, host buffers: logn[i] in {9,10}; item i's key, signature and
+ * message are pk[pk_off[i]..], sig[sig_off[i]..], msg[msg_off[i]..msg_off[i+1]). The host splits the
+ * batch by N and runs one pass per class. */
+int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
+                    const uint8_t* msg, const uint64_t* msg_off, const uint8_t* sig, const uint64_t* sig_off,
+                    int norm_policy, uint8_t* accept);
+
+/* c[i] = a[i] * b[i] in Z_q[x]/(x^n+1), q = 12289, coefficients u16 (any value; taken mod q as the
+ * ff_t constructor does, ff.hpp:69-76), results canonical. The composition ntt::ntt, polynomial::mul,
+ * ntt::intt (ntt.hpp:120-200, polynomial.hpp:99-110) exercised by tests/test_ntt.cpp:48-57.
+ * _dev: device pointers, asynchronous on `stream`. */
+int fa_polymul_many(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c);
+int fa_polymul_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c,
+                        void* stream);
+
+/* Record sizes, utils.hpp:9-17 and :39-49. */
+size_t fa_pkey_len(int logn);
+size_t fa_sig_len(int logn);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FALCON_AMD_H */

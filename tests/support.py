@@ -1,0 +1,184 @@
+"""Test-side bindings: the CPU oracle (oracle/) and the corpus generator (corpus/).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import the oracle
+binding; the product package falcon_amd never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KINDS = ["valid", "bad_sig_header", "bad_pk_header", "neg_zero", "trailing_bits", "unary_past_end",
+         "ends_at_last_bit", "k_ge_8_valid", "random_body", "bit_flip", "tampered_msg", "tampered_salt",
+         "pk_coeff_ge_q"]
+ST_OK, ST_BAD_PK_HEADER, ST_BAD_SIG_HEADER, ST_BAD_ENCODING, ST_NORM_TOO_LARGE = range(5)
+BETA2 = {9: 34034726, 10: 70265242}
+
+
+def pk_len(logn):
+    return 1 + (14 << logn) // 8
+
+
+def sig_len(logn):
+    return 666 if logn == 9 else 1280
+
+
+def _build(subdir, lib):
+    path = os.path.join(ROOT, subdir, lib)
+    src = os.path.join(ROOT, subdir, lib[3:-3] + ".c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, subdir)], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(path)
+
+
+class OracleDebug(ctypes.Structure):
+    _fields_ = [("c", ctypes.c_uint16 * 1024), ("s2", ctypes.c_int16 * 1024), ("s1", ctypes.c_int16 * 1024),
+                ("norm_exact", ctypes.c_uint64), ("norm_wrap32", ctypes.c_uint32), ("status", ctypes.c_int32),
+                ("hash_blocks", ctypes.c_int32)]
+
+
+_DBG_DTYPE = np.dtype([("c", "<u2", 1024), ("s2", "<i2", 1024), ("s1", "<i2", 1024), ("norm_exact", "<u8"),
+                       ("norm_wrap32", "<u4"), ("status", "<i4"), ("hash_blocks", "<i4")], align=True)
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def _p(a, t=ctypes.c_uint8):
+    return a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = lib = _build("oracle", "libfalcon_oracle.so")
+        lib.fo_debug_size.restype = ctypes.c_size_t
+        assert lib.fo_debug_size() == ctypes.sizeof(OracleDebug) == _DBG_DTYPE.itemsize
+        lib.fo_verify.argtypes = [ctypes.c_uint, _u8p, _u8p, ctypes.c_size_t, _u8p, ctypes.c_void_p]
+        lib.fo_verify_many.argtypes = [ctypes.c_uint, ctypes.c_size_t, _u8p, _u8p, ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.c_size_t, _u8p, _u8p, ctypes.c_void_p, ctypes.c_int]
+        lib.fo_verify_many.restype = None
+        lib.fo_shake256_xof.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t]
+        lib.fo_hash_to_point.argtypes = [ctypes.c_uint, _u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_uint16)]
+        lib.fo_decode_pkey.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_uint16)]
+        lib.fo_decompress_sig.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_int32)]
+        lib.fo_decode_sig.argtypes = [ctypes.c_uint, _u8p, _u8p, ctypes.POINTER(ctypes.c_int32)]
+        for f in (lib.fo_ntt, lib.fo_intt):
+            f.argtypes = [ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint]
+            f.restype = None
+        for f in (lib.fo_polymul, lib.fo_polymul_schoolbook):
+            f.argtypes = [ctypes.POINTER(ctypes.c_uint16)] * 3 + [ctypes.c_uint]
+            f.restype = None
+
+    def shake256(self, data: bytes, outlen: int) -> bytes:
+        src = np.frombuffer(data, dtype=np.uint8).copy() if data else np.zeros(1, np.uint8)
+        out = np.zeros(outlen, np.uint8)
+        self.lib.fo_shake256_xof(_p(src), len(data), _p(out), outlen)
+        return out.tobytes()
+
+    def hash_to_point(self, logn, salt, msg):
+        salt = np.ascontiguousarray(salt, np.uint8)
+        msg = np.ascontiguousarray(msg, np.uint8)
+        m = msg if msg.size else np.zeros(1, np.uint8)
+        c = np.zeros(1 << logn, np.uint16)
+        blocks = self.lib.fo_hash_to_point(logn, _p(salt), salt.size, _p(m), msg.size, _p(c, ctypes.c_uint16))
+        return c, blocks
+
+    def decode_pkey(self, logn, pk):
+        pk = np.ascontiguousarray(pk, np.uint8)
+        h = np.zeros(1 << logn, np.uint16)
+        ok = self.lib.fo_decode_pkey(logn, _p(pk), _p(h, ctypes.c_uint16))
+        return bool(ok), h
+
+    def decompress_sig(self, logn, sig):
+        sig = np.ascontiguousarray(sig, np.uint8)
+        s = np.zeros(1 << logn, np.int32)
+        ok = self.lib.fo_decompress_sig(logn, _p(sig), _p(s, ctypes.c_int32))
+        return bool(ok), s
+
+    def ntt(self, a, logn):
+        a = np.array(a, np.uint16)
+        self.lib.fo_ntt(_p(a, ctypes.c_uint16), logn)
+        return a
+
+    def intt(self, a, logn):
+        a = np.array(a, np.uint16)
+        self.lib.fo_intt(_p(a, ctypes.c_uint16), logn)
+        return a
+
+    def polymul(self, a, b, logn, schoolbook=False):
+        a = np.ascontiguousarray(a, np.uint16)
+        b = np.ascontiguousarray(b, np.uint16)
+        c = np.zeros(1 << logn, np.uint16)
+        f = self.lib.fo_polymul_schoolbook if schoolbook else self.lib.fo_polymul
+        f(_p(a, ctypes.c_uint16), _p(b, ctypes.c_uint16), _p(c, ctypes.c_uint16), logn)
+        return c
+
+    def verify(self, logn, pk, msg, sig):
+        """One item. Returns (flags, debug record): flags bit0 = exact64 accept, bit1 = wrap32 accept."""
+        pk = np.ascontiguousarray(pk, np.uint8)
+        sig = np.ascontiguousarray(sig, np.uint8)
+        msg = np.ascontiguousarray(msg, np.uint8)
+        m = msg if msg.size else np.zeros(1, np.uint8)
+        d = np.zeros(1, _DBG_DTYPE)
+        r = self.lib.fo_verify(logn, _p(pk), _p(m), msg.size, _p(sig), d.ctypes.data)
+        return r, d[0]
+
+    def verify_many(self, logn, pk, msg, sig, mlen=None, msg_off=None, debug=False, threads=1):
+        """Batch. pk/sig: (count, len) uint8; msg: (count, mlen) or flat bytes with msg_off[count+1].
+        Returns flags (count,) uint8 [bit0 exact64, bit1 wrap32] and the debug records (or None)."""
+        pk = np.ascontiguousarray(pk, np.uint8)
+        sig = np.ascontiguousarray(sig, np.uint8)
+        msg = np.ascontiguousarray(msg, np.uint8)
+        count = pk.shape[0]
+        assert pk.shape == (count, pk_len(logn)) and sig.shape == (count, sig_len(logn))
+        if msg_off is None:
+            mlen = msg.shape[1] if mlen is None else mlen
+            off = None
+        else:
+            off = np.ascontiguousarray(msg_off, np.uint64)
+            mlen = 0
+        m = msg if msg.size else np.zeros(1, np.uint8)
+        flags = np.zeros(count, np.uint8)
+        dbg = np.zeros(count, _DBG_DTYPE) if debug else None
+        self.lib.fo_verify_many(logn, count, _p(pk), _p(m), _p(off, ctypes.c_uint64) if off is not None else None,
+                                mlen, _p(sig), _p(flags), dbg.ctypes.data if debug else None, threads)
+        return flags, dbg
+
+
+class Corpus:
+    def __init__(self):
+        self.lib = lib = _build("corpus", "libfalcon_corpus.so")
+        lib.fc_generate.argtypes = [ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_uint32,
+                                    ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _u8p, _u8p, _u8p, _u8p]
+
+    def generate(self, logn, count, seed=1, first=0, mlen=32, malformed_permille=0, kind=-1, threads=8):
+        """Returns pk (count, pklen), msg (count, mlen), sig (count, siglen), kind (count,) as uint8 arrays."""
+        pk = np.zeros((count, pk_len(logn)), np.uint8)
+        msg = np.zeros((count, max(mlen, 1)), np.uint8)
+        sig = np.zeros((count, sig_len(logn)), np.uint8)
+        kinds = np.zeros(count, np.uint8)
+        rc = self.lib.fc_generate(logn, seed, first, count, mlen, malformed_permille, kind, threads,
+                                  _p(pk), _p(msg), _p(sig), _p(kinds))
+        assert rc == 0
+        return pk, msg[:, :mlen], sig, kinds
+
+
+_oracle = None
+_corpus = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        _oracle = Oracle()
+    return _oracle
+
+
+def corpus():
+    global _corpus
+    if _corpus is None:
+        _corpus = Corpus()
+    return _corpus
