@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- Falcon-512 batched verify throughput on MI355X (BASELINE.json config 3).
+
+A step = one pass of the verify hot path (fa_verify_many_dev: decode -> SHAKE256 -> NTT/norm
+kernels) over one batch of 2^20 distinct (public key, 32-byte message, signature) triples that
+are already resident in HBM. With --gpus N > 1 every rank verifies its own 2^20-item shard
+(independent items, no collective on the data path: "weak" scaling); rank 0 prints ONE JSON line.
+
+Extra legs on rank 0 at N == 1 (outside the timed region):
+  * cpu_baseline: the CPU oracle ("port" of the reference's falcon::verify<N>) over a bounded
+    sample of the same corpus with pthreads, plus an item-by-item comparison of the accept
+    flags with the GPU's;
+  * extras: Falcon-1024 with the malformed mix (config 4) and the n=512 batched polymul
+    (config 2) at reduced batch sizes, one timed pass each.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# Algorithmic work per unit, SURVEY.md section 8(d) (reference op-cost model, int32 lane-ops):
+#   Keccak-f[1600] = 7,440; butterfly = 11; pointwise modmul = 5; rejection sampling = 4 per draw;
+#   pk unpack = 3 and norm = 3 per coefficient; signature decode = 10 per coefficient.
+OPS_512 = {
+    "hash_kernel": 8.593 * 7440,
+    "verify_kernel": 9216 * 11 + 1024 * 5 + 546 * 4 + 512 * 3 + 512 * 3,
+    "decode_kernel": 512 * 10,
+}
+BYTES_512 = 897 + 666 + 32 + 1   # compulsory HBM bytes per verify
+PEAK_VALU_TIOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--items", type=int, default=1 << 20, help="items per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="override FA_OPT_CHUNK_ITEMS")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 18)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import falcon_amd
+    from falcon_amd import capi
+    import support
+
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    ctx = capi.Context(local_rank)
+    if args.chunk:
+        ctx.set_option(capi.OPT_CHUNK_ITEMS, args.chunk)
+
+    # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
+    n_items = args.items
+    t0 = time.time()
+    pk, msg, sig, _ = support.corpus().generate(9, n_items, seed=0xFA1C0512, first=rank * n_items, mlen=32,
+                                                threads=threads)
+    log(f"[rank {rank}] corpus: {n_items} Falcon-512 triples in {time.time() - t0:.1f}s ({threads} threads)")
+    d_pk = torch.from_numpy(pk).to(dev)
+    d_msg = torch.from_numpy(np.ascontiguousarray(msg)).to(dev)
+    d_sig = torch.from_numpy(sig).to(dev)
+    d_acc = torch.zeros(n_items, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.verify_many_dev(9, n_items, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
+                            d_acc.data_ptr(), stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.set_option(capi.OPT_PROFILE, 1)   # HIP events around every kernel, on the launch stream
+    ctx.get_profile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.get_profile()
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    accepted = int(d_acc.sum().item())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        a = torch.tensor([accepted], dtype=torch.int64, device=dev)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        accepted = int(a.item())
+
+    total_items = n_items * world * args.steps
+    value = total_items / elapsed
+    result = {
+        "metric": "Falcon-512 verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (mod q = 12289), u64 Keccak lanes",
+        "data": "synthetic",
+        "config": {"workload": "Falcon-512 batched verify, 2^20 distinct keys/signatures per GPU, 32-byte messages, "
+                               "device-resident (BASELINE.json configs[2])",
+                   "items_per_gpu": n_items, "parallelism": f"items sharded over {world} GPU(s), no collective"},
+        "accepted_fraction": accepted / (n_items * world),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (VALU-bound integer work; HBM shown beside it) ----
+        kern_ms = {"hash_kernel": prof["ms_hash"], "verify_kernel": prof["ms_verify"], "decode_kernel": prof["ms_decode"]}
+        kern_n = {"hash_kernel": prof["launches_hash"], "verify_kernel": prof["launches_verify"],
+                  "decode_kernel": prof["launches_decode"]}
+        dom = max(kern_ms, key=kern_ms.get)
+        items_per_launch = n_items * args.steps / max(kern_n[dom], 1)
+        avg_ms = kern_ms[dom] / max(kern_n[dom], 1)
+        achieved = OPS_512[dom] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "valu", "kernel": dom, "achieved": achieved, "peak": PEAK_VALU_TIOPS, "unit": "Tiop/s",
+            "frac": achieved / PEAK_VALU_TIOPS, "traffic": traffic,
+            "avg_launch_ms": avg_ms, "items_per_launch": items_per_launch, "algorithmic_ops_per_item": OPS_512[dom],
+            "note": "integer VALU work, no MFMA; peak = 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s (SURVEY.md 8d)",
+        }
+        result["kernels_ms_per_step"] = {k: v / args.steps for k, v in kern_ms.items()}
+        per_gpu_rate = n_items * args.steps / elapsed
+        result["roofline_hbm"] = {"bound": "hbm", "achieved": per_gpu_rate * BYTES_512 / 1e9, "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": per_gpu_rate * BYTES_512 / 1e9 / PEAK_HBM_GBS,
+                                  "algorithmic_bytes_per_item": BYTES_512}
+        result["whole_path_valu_frac"] = per_gpu_rate * sum(OPS_512.values()) / 1e12 / PEAK_VALU_TIOPS
+        result["retried_items"] = prof["retried_items"]
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # ---- CPU baseline: the oracle over a bounded sample of the same corpus ----
+        ns = min(args.cpu_sample, n_items)
+        orc = support.oracle()
+        t0 = time.perf_counter()
+        flags, _ = orc.verify_many(9, pk[:ns], msg[:ns], sig[:ns], threads=threads)
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        n1 = min(8192, ns)
+        orc.verify_many(9, pk[:n1], msg[:n1], sig[:n1], threads=1)
+        dt1 = time.perf_counter() - t1
+        gpu_flags = d_acc[:ns].cpu().numpy()
+        result["cpu_baseline"] = {
+            "value": ns / dt, "unit": "verifies/s", "cores": threads, "kind": "port",
+            "sample": f"first {ns} items of the same corpus, one verify per item, {threads} pthreads "
+                      f"(~{dt * threads:.0f} core-seconds); single thread: {1e6 * dt1 / n1:.1f} us/verify",
+            "single_thread_us": 1e6 * dt1 / n1,
+            "accept_mismatches_vs_gpu": int((gpu_flags != (flags & 1)).sum()),
+        }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        # Falcon-1024 with the malformed mix (BASELINE.json configs[3]) at 2^18 items
+        ne = 1 << 18
+        pk2, msg2, sig2, kinds = support.corpus().generate(10, ne, seed=0xFA1C1024, mlen=32, malformed_permille=250,
+                                                           threads=threads)
+        e_pk, e_msg, e_sig = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (pk2, msg2, sig2))
+        e_acc = torch.zeros(ne, dtype=torch.uint8, device=dev)
+
+        def step1024():
+            ctx.verify_many_dev(10, ne, e_pk.data_ptr(), e_msg.data_ptr(), None, 32, e_sig.data_ptr(),
+                                e_acc.data_ptr(), stream=stream)
+        step1024()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step1024()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        nchk = 1 << 14
+        oflags, _ = support.oracle().verify_many(10, pk2[:nchk], msg2[:nchk], sig2[:nchk], threads=threads)
+        extras["falcon1024_malformed_mix"] = {
+            "verifies_per_s": ne / dt, "items": ne, "malformed_share": float((kinds != 0).mean()),
+            "accepted_fraction": float(e_acc.float().mean().item()),
+            "accept_mismatches_vs_oracle_first_16384": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum())}
+        del e_pk, e_msg, e_sig, e_acc
+        # batched negacyclic polymul, n = 512 (BASELINE.json configs[1]) at 2^22 polynomials per operand
+        npoly = 1 << 22
+        a = torch.randint(0, 12289, (npoly, 512), dtype=torch.int32, device=dev).to(torch.int16)
+        b = torch.randint(0, 12289, (npoly, 512), dtype=torch.int32, device=dev).to(torch.int16)
+        c = torch.empty_like(a)
+        ctx.polymul_many_dev(9, npoly, a.data_ptr(), b.data_ptr(), c.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.polymul_many_dev(9, npoly, a.data_ptr(), b.data_ptr(), c.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        extras["polymul_n512"] = {"polys_per_s": npoly / dt, "polys": npoly, "hbm_GBps": npoly * 3072 / dt / 1e9}
+        result["extras"] = extras
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

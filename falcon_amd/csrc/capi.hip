@@ -40,7 +40,8 @@ uint32_t bitrev(uint32_t v, int bits)
 Tw make_tw(uint32_t w) { return Tw{ w, (uint32_t)(((uint64_t)w << 24) / Q) }; }
 
 struct Tables {
-  std::vector<Tw> fwd, inv;
+  std::vector<Tw> fwd, inv;    // reference order, ntt.hpp:62-83
+  std::vector<Tw> fwdC, invC;  // phase-C layout [lane][TWC], verify_kernel.hpp
   NttConsts nc;
 };
 Tables make_tables(int logn)
@@ -57,6 +58,24 @@ Tables make_tables(int logn)
   const uint32_t ninv = powmod(n, Q - 2);  // ntt.hpp:25-29
   t.nc.ninv = make_tw(ninv);
   t.nc.inv_last = make_tw(t.inv[1].w * ninv % Q);
+  for (int k = 0; k < 16; k++) {
+    t.nc.twA[k] = t.fwd[k];
+    t.nc.itwA[k] = t.inv[k];
+  }
+  // phase C: registers hold index bits [0, LB); the stage on bit lb uses, for lane L, the entries
+  // (N >> (lb+1)) + (L << (LB-1-lb)) + j, j < 2^(LB-1-lb), stored consecutively in the lane's row.
+  const int LB = logn - 6, PB = 6 - LB, TWC = logn == 9 ? 7 : 13;
+  t.fwdC.assign(64 * TWC, Tw{ 0, 0 });
+  t.invC.assign(64 * TWC, Tw{ 0, 0 });
+  for (uint32_t lane = 0; lane < 64; lane++) {
+    int e = 0;
+    for (int lb = PB - 1; lb >= 0; lb--)
+      for (uint32_t j = 0; j < (1u << (LB - 1 - lb)); j++, e++) {
+        const uint32_t k = (n >> (lb + 1)) + (lane << (LB - 1 - lb)) + j;
+        t.fwdC[lane * TWC + e] = t.fwd[k];
+        t.invC[lane * TWC + e] = t.inv[k];
+      }
+  }
   return t;
 }
 
@@ -94,12 +113,14 @@ struct fa_ctx {
   hipStream_t stream = nullptr;  // private stream for the host-buffer entry points
   Tw* d_tw[2] = { nullptr, nullptr };
   Tw* d_itw[2] = { nullptr, nullptr };
+  Tw* d_twc[2] = { nullptr, nullptr };
+  Tw* d_itwc[2] = { nullptr, nullptr };
   NttConsts nc[2];
-  uint32_t chunk = 65536;
+  uint32_t chunk = 1u << 20;
   uint32_t hash_blocks[2] = { 9, 17 };
   bool profile = false;
   // pipeline workspace (per chunk)
-  DevBuf hraw, s2, sqn, st2, retry_count, retry_list;
+  DevBuf hraw, s2, sqn, st2, retry_count, retry_list, slow_count, slow_list;
   // staging for the host-buffer entry points
   DevBuf h_pk, h_sig, h_msg, h_off, h_accept, h_dbg[6], h_a, h_b, h_c;
   std::vector<EventPair> events;
@@ -164,10 +185,24 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
   uint64_t* d_hraw = (uint64_t*)ctx->hraw.p;
 
-  rc = timed(ctx, s, 0, [&] {
-    hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
-                       slots, d_s2, d_sqn, d_st2);
-  });
+  if (idx) {  // re-hash pass: a handful of items, the generic decoder is enough
+    rc = timed(ctx, s, 0, [&] {
+      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
+                         slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2);
+    });
+  } else {  // fast LDS-staged decoder, then the generic one on the items that met the k >= 8 rule
+    if ((rc = ctx->slow_count.reserve(4))) return rc;
+    if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->slow_count.p, 0, 4, s));
+    uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
+    uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
+    rc = timed(ctx, s, 0, [&] {
+      hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
+                         d_st2, d_cnt, d_list);
+      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig,
+                         (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2);
+    });
+  }
   if (rc) return rc;
   rc = timed(ctx, s, 1, [&] {
     hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, sig, SIGLEN, msg,
@@ -184,6 +219,8 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   A.idx = idx;
   A.tw = ctx->d_tw[T];
   A.itw = ctx->d_itw[T];
+  A.twc = ctx->d_twc[T];
+  A.itwc = ctx->d_itwc[T];
   A.nc = ctx->nc[T];
   A.count = slots;
   A.nblk = nblk;
@@ -274,7 +311,7 @@ int polymul_dev(fa_ctx* ctx, size_t count, const uint16_t* a, const uint16_t* b,
     const size_t o = p0 << LOGN;
     const int rc = timed(ctx, s, 3, [&] {
       hipLaunchKernelGGL(polymul_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, a + o, b + o, c + o, n, ctx->d_tw[T],
-                         ctx->d_itw[T], ctx->nc[T]);
+                         ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
     });
     if (rc) return rc;
   }
@@ -326,6 +363,11 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMalloc((void**)&ctx->d_itw[t], bytes);
     if (!rc) rc = (int)hipMemcpy(ctx->d_tw[t], tb.fwd.data(), bytes, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(ctx->d_itw[t], tb.inv.data(), bytes, hipMemcpyHostToDevice);
+    const size_t cbytes = tb.fwdC.size() * sizeof(Tw);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_twc[t], cbytes);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_itwc[t], cbytes);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_twc[t], tb.fwdC.data(), cbytes, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_itwc[t], tb.invC.data(), cbytes, hipMemcpyHostToDevice);
   }
   if (rc) {
     fa_ctx_destroy(ctx);
@@ -347,8 +389,10 @@ void fa_ctx_destroy(fa_ctx* ctx)
   for (int t = 0; t < 2; t++) {
     if (ctx->d_tw[t]) (void)hipFree(ctx->d_tw[t]);
     if (ctx->d_itw[t]) (void)hipFree(ctx->d_itw[t]);
+    if (ctx->d_twc[t]) (void)hipFree(ctx->d_twc[t]);
+    if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
   }
-  DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->h_pk,
+  DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->slow_count, &ctx->slow_list, &ctx->h_pk,
                      &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_accept, &ctx->h_a, &ctx->h_b, &ctx->h_c };
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : ctx->h_dbg) b.release();

@@ -81,20 +81,25 @@ struct BitReader {
   }
 };
 
-// sig rows -> s2 (u16, lifted, natural order, row stride n), sqn[slot] = sum s2^2, st[slot].
-// idx (nullable) maps slot -> item; outputs are indexed by slot.
+// Generic decoder (every rule, including the k >= 8 windows). sig rows -> s2 (u16, lifted, natural
+// order, row stride n), sqn[o] = sum s2^2, st[o]. idx (nullable) maps slot -> item; outputs go to
+// index o = slot, or o = item when `scatter` (the fix-up pass behind decode_fast_kernel). The number
+// of slots is min(count, *dcount) when dcount is given (a device-side list length).
 template <int LOGN>
 __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __restrict__ sig,
                                                            const uint32_t* __restrict__ idx, uint32_t count,
+                                                           const uint32_t* __restrict__ dcount, bool scatter,
                                                            uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
                                                            uint8_t* __restrict__ st)
 {
   constexpr int N = 1 << LOGN;
   constexpr int SIGLEN = LOGN == 9 ? 666 : 1280;
   constexpr int32_t SLEN = 8 * SIGLEN;  // in bits, decoding.hpp:274
-  const uint32_t slot = blockIdx.x * DECODE_WG + threadIdx.x;
+  uint32_t slot = blockIdx.x * DECODE_WG + threadIdx.x;
+  if (dcount) count = min(count, *dcount);
   if (slot >= count) return;
   const uint32_t item = idx ? idx[slot] : slot;
+  if (scatter) slot = item;
   const uint8_t* row = sig + (size_t)item * SIGLEN;
   uint16_t* out = s2 + (size_t)slot * N;
 
@@ -153,6 +158,189 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
       const uint32_t t = br.peek32() >> (32 - e);
       failed |= t != 0u;
       br.skip(e);
+      pos += e;
+    }
+  }
+  st[slot] = failed ? ST_BAD_ENCODING : ST_OK;
+  sqn[slot] = norm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path: one signature per lane, but all memory traffic is wave-cooperative.
+//   * input: each lane owns a 128-byte ring in LDS that the whole wave refills with aligned 16-byte
+//     global loads (8 lanes per row), byte-swapped on the way in so a lane pulls MSB-first dwords;
+//   * output: 32 coefficients per lane are staged in LDS and written out as 64-byte row segments.
+// Only the common rule (k < 8 zeros in the unary part, 9..16 bits per coefficient) is handled here:
+// a lane that meets k == 8 stops and queues its item for decode_kernel (scatter mode), which
+// implements the window-skipping rule. Everything else (header, "-0", end-of-stream and trailing-zero
+// rules) is decided here exactly as in decode_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int DF_CH = 32;       // coefficients per chunk
+constexpr int DF_RING = 33;     // dwords per lane: 32 of ring + 1 of padding (bank-conflict free)
+constexpr int DF_OUT = 17;      // dwords per lane: 32 u16 + padding
+
+template <int LOGN>
+__global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restrict__ sig, uint32_t count,
+                                                         uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
+                                                         uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
+                                                         uint32_t* __restrict__ slow_list)
+{
+  constexpr int N = 1 << LOGN;
+  constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  constexpr uint32_t BODY = SIGLEN - 41;
+  __shared__ uint32_t ring[64 * DF_RING];
+  __shared__ uint32_t outb[64 * DF_OUT];
+  __shared__ uint32_t s_wq[64], s_tq[64];  // per row: next piece to load, piece to load up to
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t slot0 = blockIdx.x * 64u;
+  const uint32_t slot = slot0 + lane;
+  const bool live = slot < count;
+
+  // geometry of this lane's row, relative to the 16-byte aligned address `abase` below the body
+  const uintptr_t body = (uintptr_t)(sig + (size_t)(live ? slot : 0u) * SIGLEN + 41);
+  const uint32_t boff = (uint32_t)(body & 15u);
+  const uint32_t end_bits = 8u * (boff + BODY);  // first bit past the signature
+
+  // the same for the row this lane helps to load: row (lane>>3) + 8t, piece lane&7
+  // Row geometry of the 8 rows this lane helps to load is loop-invariant: keep it in registers.
+  uintptr_t rbase[8];
+  uint32_t rlast[8];  // last piece that holds a byte of the row
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const uint32_t rs = min(slot0 + (lane >> 3) + 8u * t, count - 1u);
+    const uintptr_t rbody = (uintptr_t)(sig + (size_t)rs * SIGLEN + 41);
+    rbase[t] = rbody & ~(uintptr_t)15;
+    rlast[t] = ((uint32_t)(rbody & 15u) + BODY - 1u) >> 4;
+  }
+  auto load_pieces = [&]() {
+    uint4 v[8];
+    uint32_t q[8];
+    bool want[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {  // all eight loads in flight before the first LDS write
+      const uint32_t r = (lane >> 3) + 8u * t;
+      q[t] = s_wq[r] + (lane & 7u);
+      want[t] = q[t] < s_tq[r] && q[t] <= rlast[t];
+      v[t] = *(const uint4*)(rbase[t] + 16u * (uintptr_t)min(q[t], rlast[t]));
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      if (want[t]) {
+        uint32_t* dst = ring + ((lane >> 3) + 8u * t) * DF_RING + (q[t] & 7u) * 4u;
+        dst[0] = __builtin_bswap32(v[t].x);
+        dst[1] = __builtin_bswap32(v[t].y);
+        dst[2] = __builtin_bswap32(v[t].z);
+        dst[3] = __builtin_bswap32(v[t].w);
+      }
+    }
+  };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  uint32_t rd = boff & ~3u;  // byte offset (from abase) of the next dword to pull
+  s_wq[lane] = 0u;
+  s_tq[lane] = 8u;
+  wave_sync();
+  load_pieces();
+  s_wq[lane] = 8u;
+  wave_sync();
+
+  const uint32_t* myring = ring + lane * DF_RING;
+  auto pull = [&]() -> uint32_t {
+    const uint32_t w = myring[(rd >> 2) & 31u];
+    rd += 4u;
+    return w;
+  };
+  uint64_t buf = (uint64_t)pull() << (32u + 8u * (boff & 3u));
+  int32_t nbits = 32 - 8 * (int32_t)(boff & 3u);
+  uint32_t pos = 8u * boff;  // bit position relative to abase; body bit 0 == absolute bit 328
+  int32_t i = 0;
+  uint32_t norm = 0u;
+  bool failed = false, quirk = false;
+  const bool hdr_ok = live && sig[(size_t)slot * SIGLEN] == (uint8_t)(0x30 | LOGN);
+  bool alive = hdr_ok;
+  uint16_t* orow = s2 + (size_t)slot0 * N;
+
+  for (int ch = 0; ch < N / DF_CH; ch++) {
+    uint32_t prev = 0u;
+#pragma unroll 2
+    for (int j = 0; j < DF_CH; j++) {
+      if (alive && nbits <= 32) {
+        buf |= (uint64_t)pull() << (32 - nbits);
+        nbits += 32;
+      }
+      alive = alive && pos < end_bits;  // decoding.hpp:281
+      const uint32_t top = (uint32_t)(buf >> 32);
+      const uint32_t sign = top >> 31;
+      const uint32_t k = (uint32_t)__builtin_clz((top << 8) | 0x00800000u);
+      const uint32_t mag = ((top >> 24) & 0x7fu) + (k << 7);
+      if (alive) {
+        if (k == 8u) {
+          quirk = true;
+          alive = false;
+        } else if (sign && mag == 0u) {  // decoding.hpp:327-330
+          failed = true;
+          alive = false;
+        } else {
+          buf <<= (9u + k);
+          nbits -= (int32_t)(9u + k);
+          pos += 9u + k;
+          norm += mag * mag;
+          i++;
+        }
+      }
+      const uint32_t val = sign ? Q - mag : mag;
+      if (j & 1) outb[lane * DF_OUT + (j >> 1)] = prev | (val << 16);
+      prev = val;
+    }
+    wave_sync();
+    // flush 64 rows x 64 bytes; refill every ring up to 8 pieces beyond the reader
+    if (slot0 + 64u <= count) {  // wave-uniform: full tile, no per-row guard
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        const uint32_t e = t * 64u + lane, r = e >> 4, dw = e & 15u;
+        ((uint32_t*)(orow + (size_t)r * N + ch * DF_CH))[dw] = outb[r * DF_OUT + dw];
+      }
+    } else {
+      for (int t = 0; t < 16; t++) {
+        const uint32_t e = t * 64u + lane, r = e >> 4, dw = e & 15u;
+        if (slot0 + r < count) ((uint32_t*)(orow + (size_t)r * N + ch * DF_CH))[dw] = outb[r * DF_OUT + dw];
+      }
+    }
+    s_tq[lane] = (rd >> 4) + 8u;
+    wave_sync();
+    load_pieces();
+    s_wq[lane] = s_tq[lane];
+    wave_sync();
+  }
+
+  if (!live) return;
+  if (!hdr_ok) {  // decoding.hpp:376-382
+    st[slot] = ST_BAD_SIG_HEADER;
+    sqn[slot] = 0u;
+    return;
+  }
+  if (quirk) {
+    st[slot] = ST_BAD_ENCODING;  // overwritten by the fix-up pass
+    sqn[slot] = 0u;
+    slow_list[atomicAdd(slow_count, 1u)] = slot;
+    return;
+  }
+  failed |= (pos >= end_bits) | (i < N);  // decoding.hpp:340
+  if (!failed) {  // decoding.hpp:342-357
+    while (pos < end_bits) {
+      if (nbits <= 32) {
+        buf |= (uint64_t)pull() << (32 - nbits);
+        nbits += 32;
+      }
+      const uint32_t e = min(32u, end_bits - pos);
+      failed |= ((uint32_t)(buf >> 32) >> (32u - e)) != 0u;
+      buf <<= e;
+      nbits -= (int32_t)e;
       pos += e;
     }
   }

@@ -17,8 +17,10 @@
 //   phase B  lane = (i>>6 << PB) | (i & (2^PB-1)), regs hold bits [PB, 6), PB = 6 - LB
 //   phase C  lane = i >> LB,                    regs hold bits [0, LB)
 // with two transposes through a per-wave LDS buffer in between (padded so that every
-// ds_read_b32 / ds_write_b32 is bank-conflict free). Twiddles (w, floor(w 2^24/q)) sit in an
-// LDS table per workgroup, indexed like the reference's POWERS_OF_zeta table (ntt.hpp:62-83).
+// ds_read_b32 / ds_write_b32 is bank-conflict free). Twiddles (w, floor(w 2^24/q)), indexed like the
+// reference's POWERS_OF_zeta table (ntt.hpp:62-83), come from three places: phase A's are the same
+// for every lane and arrive as kernel arguments (SGPRs); phase B's sit in a small LDS table; phase
+// C's sit in an LDS table laid out per lane (odd stride, so the ds_read_b64 are conflict free).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,12 +42,30 @@ struct Geo {
   static constexpr int PKLEN = 1 + 14 * N / 8;
   static constexpr int XBUF = N + 64;    // dwords of the padded transpose buffer
   static constexpr uint32_t BETA2 = LOGN == 9 ? 34034726u : 70265242u;  // falcon.hpp:245
+  static constexpr int TWB = N >> PB;    // phase-B twiddle indices are < N >> PB
+  static constexpr int TWC = LOGN == 9 ? 7 : 13;  // per-lane phase-C entries (odd stride; 7 resp. 12 used)
+  static constexpr int PKDW = ((PKLEN + 6) / 4 + 63) / 64;  // aligned dwords per lane covering a key row (any alignment)
+  static constexpr int MAXHW = LOGN == 9 ? 5 : 10;    // prefetched dwords of squeezed blocks per lane (9 / 17 blocks)
 };
+
+// offset of the first phase-C table entry of the stage on register bit lb (stages run lb = PB-1 .. 0,
+// the stage on bit lb uses 2^(LB-1-lb) consecutive entries)
+template <int LOGN>
+__host__ __device__ constexpr int twc_offset(int lb)
+{
+  int o = 0;
+  for (int l = Geo<LOGN>::PB - 1; l > lb; l--) o += 1 << (Geo<LOGN>::LB - 1 - l);
+  return o;
+}
 
 struct NttConsts {
   Tw ninv;      // 1/N
   Tw inv_last;  // (inverse twiddle of the last inverse stage) * 1/N
+  Tw twA[16];   // forward twiddles 0..R-1 (phase A, lane-uniform)
+  Tw itwA[16];  // inverse twiddles 0..R-1
 };
+
+enum { TW_UNIFORM = 0, TW_PHASE_B = 1, TW_PHASE_C = 2 };
 
 // element index held by (lane, reg m) in each phase
 template <int LOGN> __device__ __forceinline__ uint32_t idxA(uint32_t lane, int m) { return ((uint32_t)m << 6) | lane; }
@@ -67,24 +87,34 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Twiddle of the butterfly (m, m | 1<<lb) at global bit b. Reference index (ntt.hpp:133):
+//   (N >> (b+1)) + (i >> (b+1)),  i >> (b+1) = (lanepart << (LB-1-lb)) | (m >> (lb+1)).
+// KIND selects where it lives; `tw` is the kernel-argument array, the phase-B LDS table, or this
+// lane's row of the phase-C LDS table.
+template <int LOGN, int KIND>
+__device__ __forceinline__ Tw twiddle(const Tw* __restrict__ tw, uint32_t lanepart, int b, int lb, int m)
+{
+  constexpr int LB = Geo<LOGN>::LB, N = Geo<LOGN>::N;
+  if constexpr (KIND == TW_UNIFORM) return tw[(N >> (b + 1)) + (m >> (lb + 1))];
+  if constexpr (KIND == TW_PHASE_B) return tw[(N >> (b + 1)) + (lanepart << (LB - 1 - lb)) + (m >> (lb + 1))];
+  return tw[twc_offset<LOGN>(lb) + (m >> (lb + 1))];
+}
+
 // Cooley-Tukey stages on register bits LBTOP .. LBTOP-NST+1 of x[] (global bits BTOP ..).
-// Twiddle index of the butterfly (m, m | 1<<lb) at global bit b:  (N >> (b+1)) + (i >> (b+1)),
-// i >> (b+1) = (lanepart << (LB-1-lb)) | (m >> (lb+1))   (see the phase layouts above).
 // `since` counts stages since the last full reduction; inputs of a stage are bounded by
 // 256*((q+11) + 2q*since) < 2^24 while since <= 1, and a full reduction follows every second stage.
-template <int LOGN, int NST, int BTOP, int LBTOP>
+template <int LOGN, int NST, int BTOP, int LBTOP, int KIND>
 __device__ __forceinline__ void ct_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
                                           int& since)
 {
-  constexpr int R = Geo<LOGN>::R, LB = Geo<LOGN>::LB, N = Geo<LOGN>::N;
+  constexpr int R = Geo<LOGN>::R;
 #pragma unroll
   for (int s = 0; s < NST; s++) {
     const int b = BTOP - s, lb = LBTOP - s;
-    const Tw* base = tw + (N >> (b + 1)) + (lanepart << (LB - 1 - lb));
 #pragma unroll
     for (int m = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
-      const Tw t = base[m >> (lb + 1)];
+      const Tw t = twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
       const uint32_t v = shoup(x[m | (1 << lb)], t.w, t.wp);  // <= 256(q+48)
       x[m | (1 << lb)] = x[m] + (2u * Q256 - v);
       x[m] = x[m] + v;
@@ -98,22 +128,21 @@ __device__ __forceinline__ void ct_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw*
 }
 
 // Gentleman-Sande stages on register bits LBBOT .. LBBOT+NST-1 (global bits BBOT ..), inverse
-// twiddles; same index rule as ct_stages. Inputs of a stage are bounded by 256*(q+11)*2^since.
+// twiddles; same index rule. Inputs of a stage are bounded by 256*(q+11)*2^since.
 // LAST: the final stage of the transform also multiplies by 1/N (ntt.hpp:193-199 folded in).
-template <int LOGN, int NST, int BBOT, int LBBOT, bool LAST>
+template <int LOGN, int NST, int BBOT, int LBBOT, bool LAST, int KIND>
 __device__ __forceinline__ void gs_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
                                           int& since, const NttConsts& nc)
 {
-  constexpr int R = Geo<LOGN>::R, LB = Geo<LOGN>::LB, N = Geo<LOGN>::N;
+  constexpr int R = Geo<LOGN>::R;
 #pragma unroll
   for (int s = 0; s < NST; s++) {
     const int b = BBOT + s, lb = LBBOT + s;
     const bool last = LAST && s == NST - 1;
-    const Tw* base = tw + (N >> (b + 1)) + (lanepart << (LB - 1 - lb));
 #pragma unroll
     for (int m = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
-      const Tw t = last ? nc.inv_last : base[m >> (lb + 1)];
+      const Tw t = last ? nc.inv_last : twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
       const uint32_t u = x[m] + x[m | (1 << lb)];
       const uint32_t d = x[m] + (3u * Q256 - x[m | (1 << lb)]);
       x[m | (1 << lb)] = shoup(d, t.w, t.wp);
@@ -149,33 +178,70 @@ __device__ __forceinline__ void transpose(uint32_t (&x)[Geo<LOGN>::R], uint32_t*
   wave_lds_sync();
 }
 
+// Per-wave view of the twiddle tables.
+struct TwTabs {
+  const Tw* fA;  // kernel arguments
+  const Tw* iA;
+  const Tw* fB;  // LDS, phase B
+  const Tw* iB;
+  const Tw* fC;  // LDS, this lane's phase-C row
+  const Tw* iC;
+};
+
 // x: scaled canonical-ish (< 256*(q+11)) in phase-A layout  ->  NTT in phase-C layout, < 256*(3q+11)
 template <int LOGN>
-__device__ __forceinline__ void ntt_forward(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw,
-                                            uint32_t* __restrict__ buf, uint32_t lane)
+__device__ __forceinline__ void ntt_forward(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
+                                            uint32_t lane)
 {
   using G = Geo<LOGN>;
   int since = 0;
-  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1>(x, tw, 0u, since);
+  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u, since);
   transpose<LOGN, 0>(x, buf, lane);
-  ct_stages<LOGN, G::LB, 5, G::LB - 1>(x, tw, lane >> G::PB, since);
+  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB, since);
   transpose<LOGN, 1>(x, buf, lane);
-  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1>(x, tw, lane, since);
+  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane, since);
 }
 
-// x: < 256*(q+11)*... in phase-C layout (bit-reversed order) -> coefficients in phase-A layout,
+// x: canonical scaled, phase-C layout (bit-reversed order) -> coefficients in phase-A layout,
 // each <= 256*(q+48), already multiplied by 1/N.
 template <int LOGN>
-__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ itw,
-                                            uint32_t* __restrict__ buf, uint32_t lane, const NttConsts& nc)
+__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
+                                            uint32_t lane, const NttConsts& nc)
 {
   using G = Geo<LOGN>;
   int since = 0;
-  gs_stages<LOGN, G::PB, 0, 0, false>(x, itw, lane, since, nc);
+  gs_stages<LOGN, G::PB, 0, 0, false, TW_PHASE_C>(x, T.iC, lane, since, nc);
   transpose<LOGN, 2>(x, buf, lane);
-  gs_stages<LOGN, G::LB, G::PB, 0, false>(x, itw, lane >> G::PB, since, nc);
+  gs_stages<LOGN, G::LB, G::PB, 0, false, TW_PHASE_B>(x, T.iB, lane >> G::PB, since, nc);
   transpose<LOGN, 3>(x, buf, lane);
-  gs_stages<LOGN, G::LB, 6, 0, true>(x, itw, 0u, since, nc);
+  gs_stages<LOGN, G::LB, 6, 0, true, TW_UNIFORM>(x, T.iA, 0u, since, nc);
+}
+
+// Workgroup-shared twiddle tables in LDS and their one-time fill.
+template <int LOGN>
+struct TwLds {
+  Tw fB[Geo<LOGN>::TWB], iB[Geo<LOGN>::TWB];
+  Tw fC[64 * Geo<LOGN>::TWC], iC[64 * Geo<LOGN>::TWC];
+};
+template <int LOGN>
+__device__ __forceinline__ void fill_tw_lds(TwLds<LOGN>& L, const Tw* __restrict__ tw, const Tw* __restrict__ itw,
+                                            const Tw* __restrict__ twc, const Tw* __restrict__ itwc)
+{
+  using G = Geo<LOGN>;
+  for (int i = threadIdx.x; i < G::TWB; i += blockDim.x) {
+    L.fB[i] = tw[i];
+    L.iB[i] = itw[i];
+  }
+  for (int i = threadIdx.x; i < 64 * G::TWC; i += blockDim.x) {
+    L.fC[i] = twc[i];
+    L.iC[i] = itwc[i];
+  }
+  __syncthreads();
+}
+template <int LOGN>
+__device__ __forceinline__ TwTabs make_tabs(const TwLds<LOGN>& L, const NttConsts& nc, uint32_t lane)
+{
+  return TwTabs{ nc.twA, nc.itwA, L.fB, L.iB, L.fC + lane * Geo<LOGN>::TWC, L.iC + lane * Geo<LOGN>::TWC };
 }
 
 struct DebugOut {  // device pointers, any may be null
@@ -191,12 +257,14 @@ template <int LOGN>
 struct VerifyArgs {
   const uint8_t* pk;        // [items][PKLEN]
   const uint64_t* hraw;     // [slots][nblk*17]
-  const uint16_t* s2;       // [slots][N] lifted, natural order (decode_kernel)
+  const uint16_t* s2;       // [slots][N] lifted, natural order (decode kernels)
   const uint32_t* sqn;      // [slots]
   const uint8_t* st2;       // [slots]
   const uint32_t* idx;      // slot -> item, nullable
-  const Tw* tw;             // forward twiddles [N]
+  const Tw* tw;             // forward twiddles [N], reference order
   const Tw* itw;            // inverse twiddles [N]
+  const Tw* twc;            // phase-C tables [64][TWC]
+  const Tw* itwc;
   NttConsts nc;
   uint32_t count;           // slots
   uint32_t nblk;
@@ -208,37 +276,118 @@ struct VerifyArgs {
   DebugOut dbg;
 };
 
+// Everything one item needs from HBM, loaded one item ahead of its use so that the latency of
+// the loads hides behind the previous item's transforms.
+template <int LOGN>
+struct ItemRegs {
+  uint32_t hw[Geo<LOGN>::MAXHW];   // squeezed blocks, dword t*64+lane
+  uint32_t s2v[Geo<LOGN>::R];      // s2[m*64 + lane]
+  uint32_t pkw[Geo<LOGN>::PKDW];   // key row, aligned dword t*64+lane
+  uint32_t sqn, st, item, pal;
+};
+
+template <int LOGN>
+__device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_t slot, uint32_t lane, ItemRegs<LOGN>& r)
+{
+  using G = Geo<LOGN>;
+  r.item = A.idx ? A.idx[slot] : slot;
+  const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
+  const uint32_t ndw = A.nblk * 34u;
+#pragma unroll
+  for (int t = 0; t < G::MAXHW; t++) {
+    const uint32_t d = t * 64u + lane;
+    r.hw[t] = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are always rejected
+  }
+  const uint16_t* s2row = A.s2 + (size_t)slot * G::N;
+#pragma unroll
+  for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[idxA<LOGN>(lane, m)];
+  const uint8_t* pkrow = A.pk + (size_t)r.item * G::PKLEN;
+  r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
+  const uint32_t* pbase = (const uint32_t*)(pkrow - r.pal);
+  const uint32_t last_dw = (r.pal + (uint32_t)G::PKLEN - 1u) >> 2;
+#pragma unroll
+  for (int t = 0; t < G::PKDW; t++) {
+    const uint32_t d = t * 64u + lane;
+    r.pkw[t] = pbase[min(d, last_dw)];
+  }
+  r.sqn = A.sqn[slot];
+  r.st = A.st2[slot];
+}
+
 template <int LOGN, bool DEBUG>
 __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN> A)
 {
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
-  __shared__ Tw s_tw[N];
-  __shared__ Tw s_itw[N];
+  __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
   __shared__ uint16_t s_c[VERIFY_WAVES][N];
 
-  for (int i = threadIdx.x; i < N; i += VERIFY_WG) {
-    s_tw[i] = A.tw[i];
-    s_itw[i] = A.itw[i];
-  }
-  __syncthreads();
+  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t* buf = s_buf[wave];
+  uint32_t* pkb = s_pk[wave];
   uint16_t* cbuf = s_c[wave];
+  const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
   const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
 
-  for (uint32_t slot = blockIdx.x * VERIFY_WAVES + wave; slot < A.count; slot += nwaves) {
-    const uint32_t item = A.idx ? A.idx[slot] : slot;
-    const uint8_t* pkrow = A.pk + (size_t)item * G::PKLEN;
-    uint8_t status = A.st2[slot];
-    if (pkrow[0] != (uint8_t)LOGN) status = ST_BAD_PK_HEADER;  // falcon.hpp:240-243 comes first
-    if (status != ST_OK) {  // wave-uniform
+  uint32_t slot = blockIdx.x * VERIFY_WAVES + wave;
+  if (slot >= A.count) return;
+  ItemRegs<LOGN> cur;
+  prefetch_item<LOGN>(A, slot, lane, cur);
+
+  while (true) {
+    const uint32_t nslot = slot + nwaves;
+    const bool more = nslot < A.count;  // wave-uniform
+    ItemRegs<LOGN> nxt;
+    if (more) prefetch_item<LOGN>(A, nslot, lane, nxt);
+
+    const uint32_t item = cur.item;
+    // header byte of the key row = byte `pal` of aligned dword 0 (lane 0 holds it); falcon.hpp:240-243
+    const uint32_t hdr = (__builtin_amdgcn_readfirstlane(cur.pkw[0]) >> (8u * __builtin_amdgcn_readfirstlane(cur.pal))) & 0xffu;
+    uint32_t status = __builtin_amdgcn_readfirstlane(cur.st);
+    if (hdr != (uint32_t)LOGN) status = ST_BAD_PK_HEADER;  // checked before the signature, as the reference does
+
+    bool done = false;
+    uint32_t have = 0;  // accepted draws so far (wave-uniform)
+    if (status == ST_OK) {
+      // ---- rejection sampling (hashing.hpp:38-49): 16-bit big-endian draws in stream order ----
+      const uint32_t ndw = A.nblk * 34u;
+      auto sample = [&](uint32_t w) {
+        const uint32_t t0 = ((w & 0xffu) << 8) | ((w >> 8) & 0xffu);
+        const uint32_t t1 = ((w >> 8) & 0xff00u) | (w >> 24);
+        const bool a0 = t0 < 61445u, a1 = t1 < 61445u;
+        const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+        const uint32_t p0 = have + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
+                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        const uint32_t p1 = p0 + (a0 ? 1u : 0u);
+        if (a0 && p0 < (uint32_t)N) cbuf[p0] = (uint16_t)t0;
+        if (a1 && p1 < (uint32_t)N) cbuf[p1] = (uint16_t)t1;
+        have += __popcll(m0) + __popcll(m1);
+      };
+#pragma unroll
+      for (int t = 0; t < G::MAXHW; t++)
+        if (have < (uint32_t)N) sample(cur.hw[t]);
+      if (have < (uint32_t)N && ndw > (uint32_t)G::MAXHW * 64u) {  // re-hash pass with more blocks: not prefetched
+        const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
+        for (uint32_t base = G::MAXHW * 64u; base < ndw && have < (uint32_t)N; base += 64u) {
+          const uint32_t d = base + lane;
+          sample(d < ndw ? hrow[d] : 0xffffffffu);
+        }
+      }
+      if (have < (uint32_t)N) {  // vanishingly rare: the host re-hashes this item with more blocks
+        if (lane == 0) A.retry_list[atomicAdd(A.retry_count, 1u)] = A.item_base + item;
+        done = true;
+      }
+    }
+
+    if (status != ST_OK) {
       if (lane == 0) {
         A.accept[item] = 0;
         if (DEBUG) {
-          if (A.dbg.status) A.dbg.status[item] = status;
+          if (A.dbg.status) A.dbg.status[item] = (uint8_t)status;
           if (A.dbg.norm_exact) A.dbg.norm_exact[item] = 0ull;
           if (A.dbg.norm_wrap32) A.dbg.norm_wrap32[item] = 0u;
         }
@@ -251,97 +400,70 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
           if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = 0;
         }
       }
-      continue;
-    }
-
-    // ---- rejection sampling (hashing.hpp:38-49): 16-bit big-endian draws in stream order ----
-    const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
-    const uint32_t ndw = A.nblk * 34u;  // dwords, two draws each
-    uint32_t have = 0;                  // accepted so far (wave-uniform)
-    for (uint32_t base = 0; base < ndw && have < (uint32_t)N; base += 64u) {
-      const uint32_t d = base + lane;
-      const uint32_t w = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are rejected
-      const uint32_t t0 = ((w & 0xffu) << 8) | ((w >> 8) & 0xffu);
-      const uint32_t t1 = ((w >> 8) & 0xff00u) | (w >> 24);
-      const bool a0 = t0 < 61445u, a1 = t1 < 61445u;
-      const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      const uint32_t p0 = have + __popcll(m0 & below) + __popcll(m1 & below);
-      const uint32_t p1 = p0 + (a0 ? 1u : 0u);
-      if (a0 && p0 < (uint32_t)N) cbuf[p0] = (uint16_t)t0;
-      if (a1 && p1 < (uint32_t)N) cbuf[p1] = (uint16_t)t1;
-      have += __popcll(m0) + __popcll(m1);
-    }
-    if (have < (uint32_t)N) {  // vanishingly rare: host re-hashes this item with more blocks
-      if (lane == 0) {
-        const uint32_t at = atomicAdd(A.retry_count, 1u);
-        A.retry_list[at] = A.item_base + item;
-      }
-      continue;
-    }
-    wave_lds_sync();
-
-    // ---- s2 (already lifted to [0,q), verification.hpp:36-39) ----
-    uint32_t x[R], y[R];
-    const uint16_t* s2row = A.s2 + (size_t)slot * N;
+    } else if (!done) {
+      // ---- s2 (already lifted to [0,q), verification.hpp:36-39) ----
+      uint32_t x[R], y[R];
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = (uint32_t)s2row[idxA<LOGN>(lane, m)] << 8;
+      for (int m = 0; m < R; m++) x[m] = cur.s2v[m] << 8;
 
-    // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45),
-    //      taken mod q (equivalent to the reference's raw values) ----
-    {
-      const uint32_t pal = (uint32_t)((uintptr_t)pkrow & 3u);
-      const uint32_t* pbase = (const uint32_t*)(pkrow - pal);
-      const uint32_t last_dw = (pal + (uint32_t)G::PKLEN - 1u) >> 2;
+      // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
+      //      mod q (equivalent to the reference's raw values). The row was loaded
+      //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
+#pragma unroll
+      for (int t = 0; t < G::PKDW; t++) pkb[t * 64 + lane] = cur.pkw[t];
+      wave_lds_sync();
 #pragma unroll
       for (int m = 0; m < R; m++) {
-        const uint32_t bit = (pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
+        const uint32_t bit = (cur.pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
         const uint32_t dw = bit >> 5, sh = bit & 31u;
-        const uint32_t lo = pbase[dw], hi = pbase[min(dw + 1u, last_dw)];
+        const uint32_t lo = pkb[dw], hi = pkb[min(dw + 1u, (uint32_t)G::PKDW * 64u - 1u)];
         const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 0x3fffu;
         y[m] = csub(v, Q) << 8;
       }
-    }
 
-    ntt_forward<LOGN>(x, s_tw, buf, lane);
-    ntt_forward<LOGN>(y, s_tw, buf, lane);
+      ntt_forward<LOGN>(x, T, buf, lane);
+      ntt_forward<LOGN>(y, T, buf, lane);
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);  // polynomial.hpp:99-110
-    ntt_inverse<LOGN>(x, s_itw, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
+      for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);  // polynomial.hpp:99-110
+      ntt_inverse<LOGN>(x, T, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
 
-    // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
-    uint32_t acc = 0;
+      // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
+      uint32_t acc = 0;
 #pragma unroll
-    for (int m = 0; m < R; m++) {
-      const uint32_t i = idxA<LOGN>(lane, m);
-      const uint32_t craw = cbuf[i];                        // < 61445
-      const uint32_t r = mod_q_17(craw + 2u * Q - (x[m] >> 8));  // canonical s1
-      const uint32_t mag = r >= Q / 2u ? Q - r : r;          // |centred s1|, verification.hpp:59-68
-      acc += mag * mag;
-      if (DEBUG) {
-        if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
-        if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= Q / 2u ? (int32_t)r - (int32_t)Q : (int32_t)r);
-        if (A.dbg.s2) {
-          const uint32_t v = s2row[i];
-          A.dbg.s2[(size_t)item * N + i] = (int16_t)(v > Q / 2u ? (int32_t)v - (int32_t)Q : (int32_t)v);
+      for (int m = 0; m < R; m++) {
+        const uint32_t i = idxA<LOGN>(lane, m);
+        const uint32_t craw = cbuf[i];                              // < 61445
+        const uint32_t r = mod_q_17(craw + 2u * Q - (x[m] >> 8));   // canonical s1
+        const uint32_t mag = r >= Q / 2u ? Q - r : r;               // |centred s1|, verification.hpp:59-68
+        acc += mag * mag;
+        if (DEBUG) {
+          if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
+          if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= Q / 2u ? (int32_t)r - (int32_t)Q : (int32_t)r);
+          if (A.dbg.s2) {
+            const uint32_t v = cur.s2v[m];
+            A.dbg.s2[(size_t)item * N + i] = (int16_t)(v > Q / 2u ? (int32_t)v - (int32_t)Q : (int32_t)v);
+          }
+        }
+      }
+      unsigned long long total = acc;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o, 64);
+      total += cur.sqn;
+      const uint32_t wrapped = (uint32_t)total;
+      const bool ok = A.wrap32 ? ((int32_t)wrapped <= (int32_t)G::BETA2) : (total <= (unsigned long long)G::BETA2);
+      if (lane == 0) {
+        A.accept[item] = ok ? 1 : 0;
+        if (DEBUG) {
+          if (A.dbg.status) A.dbg.status[item] = ok ? ST_OK : ST_NORM_TOO_LARGE;
+          if (A.dbg.norm_exact) A.dbg.norm_exact[item] = total;
+          if (A.dbg.norm_wrap32) A.dbg.norm_wrap32[item] = wrapped;
         }
       }
     }
-    unsigned long long total = acc;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o, 64);
-    total += A.sqn[slot];
-    const uint32_t wrapped = (uint32_t)total;
-    const bool ok = A.wrap32 ? ((int32_t)wrapped <= (int32_t)G::BETA2) : (total <= (unsigned long long)G::BETA2);
-    if (lane == 0) {
-      A.accept[item] = ok ? 1 : 0;
-      if (DEBUG) {
-        if (A.dbg.status) A.dbg.status[item] = ok ? ST_OK : ST_NORM_TOO_LARGE;
-        if (A.dbg.norm_exact) A.dbg.norm_exact[item] = total;
-        if (A.dbg.norm_wrap32) A.dbg.norm_wrap32[item] = wrapped;
-      }
-    }
-    wave_lds_sync();  // cbuf/buf are reused by the next item
+    wave_lds_sync();  // cbuf / pkb / buf are reused by the next item
+    if (!more) break;
+    cur = nxt;
+    slot = nslot;
   }
 }
 
@@ -351,36 +473,57 @@ template <int LOGN>
 __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                             uint16_t* __restrict__ c, uint32_t count,
                                                             const Tw* __restrict__ tw, const Tw* __restrict__ itw,
+                                                            const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
                                                             const NttConsts nc)
 {
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
-  __shared__ Tw s_tw[N];
-  __shared__ Tw s_itw[N];
+  __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
-  for (int i = threadIdx.x; i < N; i += VERIFY_WG) {
-    s_tw[i] = tw[i];
-    s_itw[i] = itw[i];
-  }
-  __syncthreads();
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t* buf = s_buf[wave];
+  const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
-  for (uint32_t p = blockIdx.x * VERIFY_WAVES + wave; p < count; p += nwaves) {
+  uint32_t p = blockIdx.x * VERIFY_WAVES + wave;
+  if (p >= count) return;
+  uint32_t av[R], bv[R];
+#pragma unroll
+  for (int m = 0; m < R; m++) {
+    av[m] = a[(size_t)p * N + idxA<LOGN>(lane, m)];
+    bv[m] = b[(size_t)p * N + idxA<LOGN>(lane, m)];
+  }
+  while (true) {
+    const uint32_t np = p + nwaves;
+    const bool more = np < count;
+    uint32_t an[R], bn[R];
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < R; m++) {
+        an[m] = a[(size_t)np * N + idxA<LOGN>(lane, m)];
+        bn[m] = b[(size_t)np * N + idxA<LOGN>(lane, m)];
+      }
+    }
     uint32_t x[R], y[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
-      const size_t at = (size_t)p * N + idxA<LOGN>(lane, m);
-      x[m] = mod_q_17(a[at]) << 8;  // inputs may be any u16; the reference's ff_t ctor reduces (ff.hpp:69-76)
-      y[m] = mod_q_17(b[at]) << 8;
+      x[m] = mod_q_17(av[m]) << 8;  // inputs may be any u16; the reference's ff_t ctor reduces (ff.hpp:69-76)
+      y[m] = mod_q_17(bv[m]) << 8;
     }
-    ntt_forward<LOGN>(x, s_tw, buf, lane);
-    ntt_forward<LOGN>(y, s_tw, buf, lane);
+    ntt_forward<LOGN>(x, T, buf, lane);
+    ntt_forward<LOGN>(y, T, buf, lane);
 #pragma unroll
     for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);
-    ntt_inverse<LOGN>(x, s_itw, buf, lane, nc);
+    ntt_inverse<LOGN>(x, T, buf, lane, nc);
 #pragma unroll
-    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub(csub(x[m] >> 8, Q), Q);
+    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub(x[m] >> 8, Q);
+    if (!more) break;
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      av[m] = an[m];
+      bv[m] = bn[m];
+    }
+    p = np;
   }
 }
 

@@ -42,7 +42,7 @@ extern "C" {
 #define FA_ST_NORM_TOO_LARGE 4
 
 /* Options for fa_set_option. */
-#define FA_OPT_CHUNK_ITEMS 1     /* items per pipeline pass (workspace size), default 65536 */
+#define FA_OPT_CHUNK_ITEMS 1     /* items per pipeline pass (workspace size), default 2^20 */
 #define FA_OPT_HASH_BLOCKS_512 2 /* SHAKE256 blocks squeezed per item up front, default 9 */
 #define FA_OPT_HASH_BLOCKS_1024 3 /* default 17; items needing more are re-hashed with twice as many */
 #define FA_OPT_PROFILE 4         /* 1: record HIP events around every kernel (see fa_get_profile) */
