@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--items", type=int, default=1 << 20, help="items per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="override FA_OPT_CHUNK_ITEMS")
     ap.add_argument("--cpu-sample", type=int, default=1 << 18)
+    ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -76,6 +77,8 @@ def main():
     ctx = capi.Context(local_rank)
     if args.chunk:
         ctx.set_option(capi.OPT_CHUNK_ITEMS, args.chunk)
+    if args.no_overlap:
+        ctx.set_option(capi.OPT_OVERLAP, 0)
 
     # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
     n_items = args.items

@@ -111,6 +111,9 @@ struct fa_ctx {
   int device = 0;
   int num_cu = 256;
   hipStream_t stream = nullptr;  // private stream for the host-buffer entry points
+  hipStream_t aux = nullptr;     // decode kernels run here, beside the hash kernel on the caller's stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = false;
   Tw* d_tw[2] = { nullptr, nullptr };
   Tw* d_itw[2] = { nullptr, nullptr };
   Tw* d_twc[2] = { nullptr, nullptr };
@@ -193,15 +196,23 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   } else {  // fast LDS-staged decoder, then the generic one on the items that met the k >= 8 rule
     if ((rc = ctx->slow_count.reserve(4))) return rc;
     if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->slow_count.p, 0, 4, s));
     uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
     uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
-    rc = timed(ctx, s, 0, [&] {
-      hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
+    // The decoder is latency-bound and the hash kernel issue-bound, and neither depends on the other:
+    // they run side by side on two streams and join before the verify kernel.
+    hipStream_t ds = ctx->overlap ? ctx->aux : s;
+    if (ctx->overlap) {
+      HIP_TRY(hipEventRecord(ctx->ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(ds, ctx->ev_fork, 0));
+    }
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, ds));
+    rc = timed(ctx, ds, 0, [&] {
+      hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, ds, sig, slots, d_s2, d_sqn,
                          d_st2, d_cnt, d_list);
-      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig,
+      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, ds, sig,
                          (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2);
     });
+    if (!rc && ctx->overlap) rc = (int)hipEventRecord(ctx->ev_join, ds);
   }
   if (rc) return rc;
   rc = timed(ctx, s, 1, [&] {
@@ -209,6 +220,7 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
                        msg_off, mlen, idx, slots, nblk, d_hraw);
   });
   if (rc) return rc;
+  if (!idx && ctx->overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
 
   VerifyArgs<LOGN> A;
   A.pk = pk;
@@ -354,6 +366,9 @@ int fa_ctx_create(int device, fa_ctx** out)
   if (!rc) {
     ctx->num_cu = prop.multiProcessorCount;
     rc = (int)hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (!rc) rc = (int)hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
   }
   for (int t = 0; t < 2 && !rc; t++) {
     const Tables tb = make_tables(9 + t);
@@ -382,6 +397,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
   if (!ctx) return;
   Guard g(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
   for (auto& e : ctx->events) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -397,6 +413,9 @@ void fa_ctx_destroy(fa_ctx* ctx)
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : ctx->h_dbg) b.release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
 }
 
@@ -415,6 +434,9 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
       return 0;
     case FA_OPT_PROFILE:
       ctx->profile = value != 0;
+      return 0;
+    case FA_OPT_OVERLAP:
+      ctx->overlap = value != 0;
       return 0;
     default:
       return FA_E_ARG;

@@ -42,7 +42,12 @@ __device__ __forceinline__ u64s rotl64(u64s v)
   }
 }
 
-__device__ __forceinline__ u64s xor3(u64s a, u64s b, u64s c) { return u64s{ a.lo ^ b.lo ^ c.lo, a.hi ^ b.hi ^ c.hi }; }
+// three-input XOR in one v_bitop3_b32 (truth table 0x96); hipcc does not form it from a ^ b ^ c by itself
+__device__ __forceinline__ u64s xor3(u64s a, u64s b, u64s c)
+{
+  return u64s{ (uint32_t)__builtin_amdgcn_bitop3_b32((int)a.lo, (int)b.lo, (int)c.lo, 0x96),
+               (uint32_t)__builtin_amdgcn_bitop3_b32((int)a.hi, (int)b.hi, (int)c.hi, 0x96) };
+}
 __device__ __forceinline__ u64s chi(u64s a, u64s b, u64s c) { return u64s{ a.lo ^ (~b.lo & c.lo), a.hi ^ (~b.hi & c.hi) }; }
 
 // One Keccak-f[1600] round on a[x + 5y].
@@ -117,7 +122,10 @@ constexpr int HASH_WG = 256;
 // mlen at msg + item*mlen when msg_off == nullptr, else msg + msg_off[item] with length
 // msg_off[item+1] - msg_off[item] (may differ per lane: the absorb loop diverges, the squeeze
 // loop does not). idx (nullable) maps output slot -> item.
-__global__ __launch_bounds__(HASH_WG) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
+#ifndef FA_HASH_WAVES
+#define FA_HASH_WAVES 4
+#endif
+__global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
                                                        const uint8_t* __restrict__ msg,
                                                        const uint64_t* __restrict__ msg_off, uint32_t mlen,
                                                        const uint32_t* __restrict__ idx, uint32_t count,
