@@ -492,17 +492,24 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
   Guard g(ctx->device);
   if (g.err) return g.err;
   const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);
-  const size_t msg_bytes = msg_off ? (size_t)msg_off[count] : count * (size_t)mlen;
+  // With offsets only the window [msg_off[0], msg_off[count]) is staged (a shard of a larger batch
+  // passes a window of the global offset array); it lands at byte (first & 3) of the staging buffer
+  // so that the device-side base pointer `h_msg - (first & ~3)` stays 4-byte aligned.
+  const size_t first = msg_off ? (size_t)msg_off[0] : 0;
+  if (msg_off && (size_t)msg_off[count] < first) return FA_E_ARG;
+  const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;
   hipStream_t s = ctx->stream;
   int rc;
   // +8 bytes of slack: the kernels read whole aligned dwords around the last record
   if ((rc = ctx->h_pk.reserve(count * pklen + 8))) return rc;
   if ((rc = ctx->h_sig.reserve(count * siglen + 8))) return rc;
-  if ((rc = ctx->h_msg.reserve(msg_bytes + 8))) return rc;
+  if ((rc = ctx->h_msg.reserve(msg_bytes + 12))) return rc;
   if ((rc = ctx->h_accept.reserve(count))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, pk, count * pklen, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->h_sig.p, sig, count * siglen, hipMemcpyHostToDevice, s));
-  if (msg_bytes) HIP_TRY(hipMemcpyAsync(ctx->h_msg.p, msg, msg_bytes, hipMemcpyHostToDevice, s));
+  uint8_t* d_msg_stage = (uint8_t*)ctx->h_msg.p + (first & 3u);
+  if (msg_bytes) HIP_TRY(hipMemcpyAsync(d_msg_stage, msg + first, msg_bytes, hipMemcpyHostToDevice, s));
+  const uint8_t* d_msg = d_msg_stage - first;  // message i starts at d_msg + msg_off[i]
   const uint64_t* d_off = nullptr;
   if (msg_off) {
     if ((rc = ctx->h_off.reserve((count + 1) * 8))) return rc;
@@ -521,7 +528,7 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
       *dev[i] = ctx->h_dbg[i].p;
     }
   }
-  rc = fa_verify_many_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, (const uint8_t*)ctx->h_msg.p, d_off, mlen,
+  rc = fa_verify_many_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, d_msg, d_off, mlen,
                           (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(accept, ctx->h_accept.p, count, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,162 @@
+// falcon_amd.hpp -- C++20 host side of the MI355X batched Falcon verifier.
+//
+// Keeps the reference's verify API surface and adds the batch entry point (BASELINE.json
+// north_star). Each function names the reference interface it stands in for (file:line under the
+// reference tree):
+//
+//   falcon::verify<N>(pkey, msg, mlen, sig)            falcon.hpp:230-249   same signature, same bool
+//   falcon::verify_many<N>(count, pkeys, msgs, ...)    no counterpart: `count` independent calls of the above
+//
+// Both run on the GPU through the C ABI of falcon_amd.h (libfalcon_amd.so); there is no CPU path
+// in this header. Conventions are the reference's: the caller owns every
+// buffer, record lengths are implied by N (utils.hpp:9-17,39-49), the only per-item result is the
+// bool / accept byte. Errors of the device layer (no GPU, out of memory) are not representable in
+// the reference's `bool`, so they throw falcon::device_error.
+//
+// A context (device tables + workspace) is created per (thread, device) on first use, so the
+// functions are safe to call concurrently from any number of threads, as the reference's are.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <exception>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "falcon_amd.h"
+
+namespace falcon {
+
+struct device_error : std::runtime_error {
+  int code;
+  device_error(const char* what, int c) : std::runtime_error(std::string(what) + ": " + fa_strerror(c)), code(c) {}
+};
+
+// Norm policy, SURVEY.md section 0.1: `exact` is what verification.hpp:70-79 means and what a
+// clang++-built reference returns; `wrap32` reproduces a g++-built reference on invalid inputs.
+enum class norm_policy : int { exact = FA_NORM_EXACT64, wrap32 = FA_NORM_WRAP32 };
+
+namespace detail {
+
+template<size_t N>
+constexpr int logn()
+{
+  static_assert(N == 512 || N == 1024, "N must be 512 or 1024");  // falcon.hpp:236
+  return N == 512 ? 9 : 10;
+}
+
+// One context per (thread, device), destroyed at thread exit.
+class context_cache
+{
+public:
+  fa_ctx* get(int device)
+  {
+    for (auto& s : slots_)
+      if (s.ctx && s.device == device) return s.ctx;
+    for (auto& s : slots_) {
+      if (s.ctx) continue;
+      const int rc = fa_ctx_create(device, &s.ctx);
+      if (rc) throw device_error("fa_ctx_create", rc);
+      s.device = device;
+      return s.ctx;
+    }
+    throw device_error("fa_ctx_create (more than 16 devices per thread)", FA_E_ARG);
+  }
+  ~context_cache()
+  {
+    for (auto& s : slots_)
+      if (s.ctx) fa_ctx_destroy(s.ctx);
+  }
+
+private:
+  struct slot {
+    fa_ctx* ctx = nullptr;
+    int device = -1;
+  };
+  slot slots_[16];
+};
+
+inline fa_ctx* context(int device)
+{
+  thread_local context_cache cache;
+  return cache.get(device);
+}
+
+}  // namespace detail
+
+// Record sizes, utils.hpp:9-17 and :39-49.
+template<size_t N> constexpr size_t pkey_len() { return 1 + 14 * N / 8; }
+template<size_t N> constexpr size_t sig_len() { return N == 512 ? 666 : 1280; }
+
+// Batch of `count` independent falcon::verify<N> calls (falcon.hpp:230-249).
+//   pkeys  count * pkey_len<N>() bytes, sigs  count * sig_len<N>() bytes, contiguous records;
+//   msgs   msg_off == nullptr: message i is the mlen bytes at msgs + i*mlen,
+//          else message i is msgs[msg_off[i] .. msg_off[i+1]) and mlen is ignored;
+//   accept one byte per item: 1 iff the reference returns true for that triple.
+template<size_t N>
+inline void verify_many(size_t count, const uint8_t* pkeys, const uint8_t* msgs, size_t mlen, const uint64_t* msg_off,
+                        const uint8_t* sigs, uint8_t* accept, int device = 0, norm_policy policy = norm_policy::exact,
+                        const fa_debug* debug = nullptr)
+{
+  const int rc = fa_verify_many(detail::context(device), detail::logn<N>(), count, pkeys, msgs, msg_off, (uint32_t)mlen,
+                                sigs, (int)policy, accept, debug);
+  if (rc) throw device_error("fa_verify_many", rc);
+}
+
+// The same on buffers that already live in the HBM of `device` (hipMalloc'ed, 4-byte aligned);
+// `stream` is a hipStream_t. The call returns after the stream has been synchronised once.
+template<size_t N>
+inline void verify_many_device(size_t count, const uint8_t* d_pkeys, const uint8_t* d_msgs, size_t mlen,
+                               const uint64_t* d_msg_off, const uint8_t* d_sigs, uint8_t* d_accept, int device = 0,
+                               void* stream = nullptr, norm_policy policy = norm_policy::exact)
+{
+  const int rc = fa_verify_many_dev(detail::context(device), detail::logn<N>(), count, d_pkeys, d_msgs, d_msg_off,
+                                    (uint32_t)mlen, d_sigs, (int)policy, d_accept, nullptr, stream);
+  if (rc) throw device_error("fa_verify_many_dev", rc);
+}
+
+// Multi-GPU form: the batch is cut into `ndev` contiguous ranges of
+// ceil(count/ndev) items, range g goes to device first_device+g on its own host thread and context,
+// and every range writes its slice of `accept` -- items are independent, so there is no collective
+// and nothing to merge beyond that concatenation. Messages must be fixed-stride or offset-indexed
+// as above (offsets are global, so every shard reads the same msgs/msg_off arrays).
+template<size_t N>
+inline void verify_many_sharded(size_t count, const uint8_t* pkeys, const uint8_t* msgs, size_t mlen,
+                                const uint64_t* msg_off, const uint8_t* sigs, uint8_t* accept, int ndev,
+                                int first_device = 0, norm_policy policy = norm_policy::exact)
+{
+  if (ndev < 1) throw device_error("verify_many_sharded", FA_E_ARG);
+  const size_t per = (count + (size_t)ndev - 1) / (size_t)ndev;
+  std::vector<std::thread> workers;
+  std::vector<std::exception_ptr> errors((size_t)ndev);
+  for (int g = 0; g < ndev; g++) {
+    const size_t lo = per * (size_t)g, hi = lo + per < count ? lo + per : count;
+    if (lo >= hi) break;
+    workers.emplace_back([=, &errors] {
+      try {
+        // with msg_off the shard passes the whole message array and its own window of offsets
+        verify_many<N>(hi - lo, pkeys + lo * pkey_len<N>(), msg_off ? msgs : msgs + lo * mlen, mlen,
+                       msg_off ? msg_off + lo : nullptr, sigs + lo * sig_len<N>(), accept + lo, first_device + g, policy);
+      } catch (...) {
+        errors[(size_t)g] = std::current_exception();
+      }
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (auto& e : errors)
+    if (e) std::rethrow_exception(e);
+}
+
+// falcon.hpp:230-249. `sig` is non-const there too (never written).
+template<size_t N>
+static inline bool verify(const uint8_t* __restrict pkey, const uint8_t* __restrict msg, const size_t mlen,
+                          uint8_t* __restrict sig)
+  requires((N == 512) || (N == 1024))
+{
+  uint8_t ok = 0;
+  verify_many<N>(1, pkey, msg, mlen, nullptr, sig, &ok);
+  return ok != 0;
+}
+
+}  // namespace falcon
