@@ -37,7 +37,15 @@ uint32_t bitrev(uint32_t v, int bits)
   for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
   return r;
 }
-Tw make_tw(uint32_t w) { return Tw{ w, (uint32_t)(((uint64_t)w << 24) / Q) }; }
+// centred twiddle and its Shoup companion round(w * 2^32 / q), zq.hpp
+Tw make_tw(uint32_t w)
+{
+  const int64_t wc = w > Q / 2 ? (int64_t)w - (int64_t)Q : (int64_t)w;
+  const int64_t num = 2 * (wc * ((int64_t)1 << 32)) + (int64_t)Q, den = 2 * (int64_t)Q;
+  int64_t wp = num / den;
+  if (num % den < 0) wp--;  // floor division
+  return Tw{ (int32_t)wc, (int32_t)wp };
+}
 
 struct Tables {
   std::vector<Tw> fwd, inv;    // reference order, ntt.hpp:62-83
@@ -50,14 +58,16 @@ Tables make_tables(int logn)
   Tables t;
   t.fwd.resize(n);
   t.inv.resize(n);
+  uint32_t inv1 = 1;  // canonical inverse twiddle of index 1
   for (uint32_t k = 0; k < n; k++) {
-    const uint32_t w = powmod(zeta, bitrev(k, logn));
+    const uint32_t w = powmod(zeta, bitrev(k, logn)), wi = powmod(w, Q - 2);
     t.fwd[k] = make_tw(w);
-    t.inv[k] = make_tw(powmod(w, Q - 2));
+    t.inv[k] = make_tw(wi);
+    if (k == 1) inv1 = wi;
   }
   const uint32_t ninv = powmod(n, Q - 2);  // ntt.hpp:25-29
   t.nc.ninv = make_tw(ninv);
-  t.nc.inv_last = make_tw(t.inv[1].w * ninv % Q);
+  t.nc.inv_last = make_tw(inv1 * ninv % Q);
   for (int k = 0; k < 16; k++) {
     t.nc.twA[k] = t.fwd[k];
     t.nc.itwA[k] = t.inv[k];

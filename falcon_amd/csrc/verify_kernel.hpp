@@ -17,7 +17,7 @@
 //   phase B  lane = (i>>6 << PB) | (i & (2^PB-1)), regs hold bits [PB, 6), PB = 6 - LB
 //   phase C  lane = i >> LB,                    regs hold bits [0, LB)
 // with two transposes through a per-wave LDS buffer in between (padded so that every
-// ds_read_b32 / ds_write_b32 is bank-conflict free). Twiddles (w, floor(w 2^24/q)), indexed like the
+// ds_read_b32 / ds_write_b32 is bank-conflict free). Twiddles (w, round(w 2^32/q)), indexed like the
 // reference's POWERS_OF_zeta table (ntt.hpp:62-83), come from three places: phase A's are the same
 // for every lane and arrive as kernel arguments (SGPRs); phase B's sit in a small LDS table; phase
 // C's sit in an LDS table laid out per lane (odd stride, so the ds_read_b64 are conflict free).
@@ -80,6 +80,19 @@ template <int LOGN> __device__ __forceinline__ uint32_t idxC(uint32_t lane, int 
 template <int LOGN> __device__ __forceinline__ uint32_t padAB(uint32_t i) { return i + (i >> 6) * (64u / Geo<LOGN>::R); }
 template <int LOGN> __device__ __forceinline__ uint32_t padBC(uint32_t i) { return i + (i >> Geo<LOGN>::LB); }
 
+// Sum of v over the 64 lanes (v < 2^26 per lane), returned wave-uniform. Six DPP adds: within rows of
+// 16 lanes by row_shr, then across rows by row_bcast; lane 63 ends up holding the total.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ void wave_lds_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -101,11 +114,9 @@ __device__ __forceinline__ Tw twiddle(const Tw* __restrict__ tw, uint32_t lanepa
 }
 
 // Cooley-Tukey stages on register bits LBTOP .. LBTOP-NST+1 of x[] (global bits BTOP ..).
-// `since` counts stages since the last full reduction; inputs of a stage are bounded by
-// 256*((q+11) + 2q*since) < 2^24 while since <= 1, and a full reduction follows every second stage.
+// Values are lazy signed residues (zq.hpp): a stage widens the bound by q, nothing is reduced.
 template <int LOGN, int NST, int BTOP, int LBTOP, int KIND>
-__device__ __forceinline__ void ct_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
-                                          int& since)
+__device__ __forceinline__ void ct_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart)
 {
   constexpr int R = Geo<LOGN>::R;
 #pragma unroll
@@ -115,24 +126,20 @@ __device__ __forceinline__ void ct_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw*
     for (int m = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
       const Tw t = twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      const uint32_t v = shoup(x[m | (1 << lb)], t.w, t.wp);  // <= 256(q+48)
-      x[m | (1 << lb)] = x[m] + (2u * Q256 - v);
+      const int32_t v = shoup(x[m | (1 << lb)], t.w, t.wp);  // [0, q]
+      x[m | (1 << lb)] = x[m] - v;
       x[m] = x[m] + v;
-    }
-    if (++since == 2) {
-#pragma unroll
-      for (int m = 0; m < R; m++) x[m] = reduce(x[m]);
-      since = 0;
     }
   }
 }
 
 // Gentleman-Sande stages on register bits LBBOT .. LBBOT+NST-1 (global bits BBOT ..), inverse
-// twiddles; same index rule. Inputs of a stage are bounded by 256*(q+11)*2^since.
+// twiddles; same index rule. All values are >= 0 here (sums of values in [0, q]); the sums double
+// per stage, so with REDUCE the sum outputs of the last stage are brought back to [0, q].
 // LAST: the final stage of the transform also multiplies by 1/N (ntt.hpp:193-199 folded in).
-template <int LOGN, int NST, int BBOT, int LBBOT, bool LAST, int KIND>
-__device__ __forceinline__ void gs_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
-                                          int& since, const NttConsts& nc)
+template <int LOGN, int NST, int BBOT, int LBBOT, bool LAST, bool REDUCE, int KIND>
+__device__ __forceinline__ void gs_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
+                                          const NttConsts& nc)
 {
   constexpr int R = Geo<LOGN>::R;
 #pragma unroll
@@ -143,37 +150,32 @@ __device__ __forceinline__ void gs_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw*
     for (int m = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
       const Tw t = last ? nc.inv_last : twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      const uint32_t u = x[m] + x[m | (1 << lb)];
-      const uint32_t d = x[m] + (3u * Q256 - x[m | (1 << lb)]);
+      const int32_t u = x[m] + x[m | (1 << lb)];
+      const int32_t d = x[m] - x[m | (1 << lb)];
       x[m | (1 << lb)] = shoup(d, t.w, t.wp);
-      x[m] = last ? shoup(u, nc.ninv.w, nc.ninv.wp) : u;
-    }
-    if (!last && ++since == 2) {
-#pragma unroll
-      for (int m = 0; m < R; m++) x[m] = reduce(x[m]);
-      since = 0;
+      x[m] = last ? shoup(u, nc.ninv.w, nc.ninv.wp) : (REDUCE && s == NST - 1) ? reduce(u) : u;
     }
   }
 }
 
 template <int LOGN, int PHASE_FROM>  // 0: A->B, 1: B->C, 2: C->B, 3: B->A
-__device__ __forceinline__ void transpose(uint32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
+__device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
 {
   constexpr int R = Geo<LOGN>::R;
 #pragma unroll
   for (int m = 0; m < R; m++) {
-    if constexpr (PHASE_FROM == 0) buf[padAB<LOGN>(idxA<LOGN>(lane, m))] = x[m];
-    if constexpr (PHASE_FROM == 1) buf[padBC<LOGN>(idxB<LOGN>(lane, m))] = x[m];
-    if constexpr (PHASE_FROM == 2) buf[padBC<LOGN>(idxC<LOGN>(lane, m))] = x[m];
-    if constexpr (PHASE_FROM == 3) buf[padAB<LOGN>(idxB<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 0) buf[padAB<LOGN>(idxA<LOGN>(lane, m))] = (uint32_t)x[m];
+    if constexpr (PHASE_FROM == 1) buf[padBC<LOGN>(idxB<LOGN>(lane, m))] = (uint32_t)x[m];
+    if constexpr (PHASE_FROM == 2) buf[padBC<LOGN>(idxC<LOGN>(lane, m))] = (uint32_t)x[m];
+    if constexpr (PHASE_FROM == 3) buf[padAB<LOGN>(idxB<LOGN>(lane, m))] = (uint32_t)x[m];
   }
   wave_lds_sync();
 #pragma unroll
   for (int m = 0; m < R; m++) {
-    if constexpr (PHASE_FROM == 0) x[m] = buf[padAB<LOGN>(idxB<LOGN>(lane, m))];
-    if constexpr (PHASE_FROM == 1) x[m] = buf[padBC<LOGN>(idxC<LOGN>(lane, m))];
-    if constexpr (PHASE_FROM == 2) x[m] = buf[padBC<LOGN>(idxB<LOGN>(lane, m))];
-    if constexpr (PHASE_FROM == 3) x[m] = buf[padAB<LOGN>(idxA<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 0) x[m] = (int32_t)buf[padAB<LOGN>(idxB<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 1) x[m] = (int32_t)buf[padBC<LOGN>(idxC<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 2) x[m] = (int32_t)buf[padBC<LOGN>(idxB<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 3) x[m] = (int32_t)buf[padAB<LOGN>(idxA<LOGN>(lane, m))];
   }
   wave_lds_sync();
 }
@@ -188,33 +190,33 @@ struct TwTabs {
   const Tw* iC;
 };
 
-// x: scaled canonical-ish (< 256*(q+11)) in phase-A layout  ->  NTT in phase-C layout, < 256*(3q+11)
+// x: |x| < 2^16 in phase-A layout  ->  NTT in phase-C layout, |x| < 2^16 + logn*q
 template <int LOGN>
-__device__ __forceinline__ void ntt_forward(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
+__device__ __forceinline__ void ntt_forward(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
                                             uint32_t lane)
 {
   using G = Geo<LOGN>;
-  int since = 0;
-  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u, since);
+  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
   transpose<LOGN, 0>(x, buf, lane);
-  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB, since);
+  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB);
   transpose<LOGN, 1>(x, buf, lane);
-  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane, since);
+  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane);
 }
 
-// x: canonical scaled, phase-C layout (bit-reversed order) -> coefficients in phase-A layout,
-// each <= 256*(q+48), already multiplied by 1/N.
+// x: in [0, q], phase-C layout (bit-reversed order) -> coefficients in phase-A layout, each in
+// [0, q], already multiplied by 1/N. Phases C and B are six stages together (bound 64q < 2^19 on
+// the differences fed to shoup), so one reduction of the sums after phase B is enough.
 template <int LOGN>
-__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
+__device__ __forceinline__ void ntt_inverse(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
                                             uint32_t lane, const NttConsts& nc)
 {
   using G = Geo<LOGN>;
-  int since = 0;
-  gs_stages<LOGN, G::PB, 0, 0, false, TW_PHASE_C>(x, T.iC, lane, since, nc);
+  static_assert(G::PB + G::LB == 6, "phases C and B together are six stages");
+  gs_stages<LOGN, G::PB, 0, 0, false, false, TW_PHASE_C>(x, T.iC, lane, nc);
   transpose<LOGN, 2>(x, buf, lane);
-  gs_stages<LOGN, G::LB, G::PB, 0, false, TW_PHASE_B>(x, T.iB, lane >> G::PB, since, nc);
+  gs_stages<LOGN, G::LB, G::PB, 0, false, true, TW_PHASE_B>(x, T.iB, lane >> G::PB, nc);
   transpose<LOGN, 3>(x, buf, lane);
-  gs_stages<LOGN, G::LB, 6, 0, true, TW_UNIFORM>(x, T.iA, 0u, since, nc);
+  gs_stages<LOGN, G::LB, 6, 0, true, false, TW_UNIFORM>(x, T.iA, 0u, nc);
 }
 
 // Workgroup-shared twiddle tables in LDS and their one-time fill.
@@ -290,7 +292,9 @@ template <int LOGN>
 __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_t slot, uint32_t lane, ItemRegs<LOGN>& r)
 {
   using G = Geo<LOGN>;
+  slot = __builtin_amdgcn_readfirstlane(slot);  // wave-uniform: row bases become scalar, lanes add 32-bit offsets
   r.item = A.idx ? A.idx[slot] : slot;
+  r.item = __builtin_amdgcn_readfirstlane(r.item);
   const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
   const uint32_t ndw = A.nblk * 34u;
 #pragma unroll
@@ -402,12 +406,12 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
       }
     } else if (!done) {
       // ---- s2 (already lifted to [0,q), verification.hpp:36-39) ----
-      uint32_t x[R], y[R];
+      int32_t x[R], y[R];
 #pragma unroll
-      for (int m = 0; m < R; m++) x[m] = cur.s2v[m] << 8;
+      for (int m = 0; m < R; m++) x[m] = (int32_t)cur.s2v[m];
 
       // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
-      //      mod q (equivalent to the reference's raw values). The row was loaded
+      //      lazily (equivalent to the reference's raw values). The row was loaded
       //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
 #pragma unroll
       for (int t = 0; t < G::PKDW; t++) pkb[t * 64 + lane] = cur.pkw[t];
@@ -417,14 +421,14 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
         const uint32_t bit = (cur.pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
         const uint32_t dw = bit >> 5, sh = bit & 31u;
         const uint32_t lo = pkb[dw], hi = pkb[min(dw + 1u, (uint32_t)G::PKDW * 64u - 1u)];
-        const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 0x3fffu;
-        y[m] = csub(v, Q) << 8;
+        const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, sh) & 0x3fffu;
+        y[m] = (int32_t)v;  // <= 16383, reduced by the transform itself
       }
 
       ntt_forward<LOGN>(x, T, buf, lane);
       ntt_forward<LOGN>(y, T, buf, lane);
 #pragma unroll
-      for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);  // polynomial.hpp:99-110
+      for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));  // polynomial.hpp:99-110
       ntt_inverse<LOGN>(x, T, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
 
       // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
@@ -433,9 +437,10 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
       for (int m = 0; m < R; m++) {
         const uint32_t i = idxA<LOGN>(lane, m);
         const uint32_t craw = cbuf[i];                              // < 61445
-        const uint32_t r = mod_q_17(craw + 2u * Q - (x[m] >> 8));   // canonical s1
-        const uint32_t mag = r >= Q / 2u ? Q - r : r;               // |centred s1|, verification.hpp:59-68
-        acc += mag * mag;
+        const uint32_t r0 = (uint32_t)reduce((int32_t)craw - x[m]); // s1 in [0, q] (x[m] in [0, q])
+        const uint32_t mag = r0 >= Q / 2u ? Q - r0 : r0;            // |centred s1|, verification.hpp:59-68 (q -> 0)
+        acc += mul24(mag, mag);
+        const uint32_t r = DEBUG ? csub(r0, Q) : r0;                // canonical s1, debug output only
         if (DEBUG) {
           if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
           if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= Q / 2u ? (int32_t)r - (int32_t)Q : (int32_t)r);
@@ -445,9 +450,9 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
           }
         }
       }
-      unsigned long long total = acc;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o, 64);
+      // per-lane sums are < 2^30 but the wave total needs 36 bits: reduce the low 24 bits and the rest apart
+      unsigned long long total = (unsigned long long)wave_sum_u32(acc & 0xffffffu) +
+                                 ((unsigned long long)wave_sum_u32(acc >> 24) << 24);
       total += cur.sqn;
       const uint32_t wrapped = (uint32_t)total;
       const bool ok = A.wrap32 ? ((int32_t)wrapped <= (int32_t)G::BETA2) : (total <= (unsigned long long)G::BETA2);
@@ -504,19 +509,19 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
         bn[m] = b[(size_t)np * N + idxA<LOGN>(lane, m)];
       }
     }
-    uint32_t x[R], y[R];
+    int32_t x[R], y[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
-      x[m] = mod_q_17(av[m]) << 8;  // inputs may be any u16; the reference's ff_t ctor reduces (ff.hpp:69-76)
-      y[m] = mod_q_17(bv[m]) << 8;
+      x[m] = (int32_t)av[m];  // inputs may be any u16 (the reference's ff_t ctor reduces, ff.hpp:69-76): lazy residues
+      y[m] = (int32_t)bv[m];
     }
     ntt_forward<LOGN>(x, T, buf, lane);
     ntt_forward<LOGN>(y, T, buf, lane);
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = mulmod_scaled(x[m] >> 8, y[m] >> 8);
+    for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));
     ntt_inverse<LOGN>(x, T, buf, lane, nc);
 #pragma unroll
-    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub(x[m] >> 8, Q);
+    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)x[m], Q);
     if (!more) break;
 #pragma unroll
     for (int m = 0; m < R; m++) {

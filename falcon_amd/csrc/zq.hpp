@@ -2,14 +2,20 @@
 //
 // Replaces the reference's Barrett ff_t (ff.hpp:64-167). Any exact reduction yields the same
 // canonical residues, so parity is unaffected; the form below is chosen
-// for the CDNA4 vector ALU:
-//   * values live in VGPRs as X = 256*x ("scaled"), x < 2^16, so X < 2^24 and both factors of
-//     every product fit the full-rate 24-bit multipliers (v_mul_u32_u24, v_mul_hi_u32_u24,
-//     v_mad_i32_i24); the quarter-rate v_mul_lo_u32 is never used on the butterfly path;
-//   * a twiddle w is stored with its Shoup companion wp = floor(w * 2^24 / q); then
-//       shoup(X, w, wp) = 256 * (w*x - floor(wp*x / 2^24) * q),   in [0, 256*(q + 48)]
-//     costs exactly three VALU instructions (mul_hi_u24, mul_u24, mad_i24);
-//   * sums and differences are lazy: a full reduction (shoup by 1) runs every second stage.
+// for the CDNA4 vector ALU, where every integer multiply (24- or 32-bit, low or high half) issues
+// at the same half rate and adds/subtracts at full rate (profiles/valu_peak_r01.json):
+//   * values live in VGPRs as signed 32-bit integers that are only congruent to the residue
+//     ("lazy"), with |x| < 2^19 wherever x feeds a multiplication;
+//   * a twiddle w is stored centred, w in (-q/2, q/2), with its Shoup companion
+//     wp = round(w * 2^32 / q); then
+//       shoup(x, w, wp) = x*w - floor(x*wp / 2^32) * q   is in [0, q]   for |x| < 2^19
+//     and costs exactly three VALU instructions (v_mul_hi_i32, v_mul_i32_i24, v_mad_i32_i24);
+//   * a butterfly is shoup + one add + one subtract: sums and differences are never reduced in
+//     the forward transform (the bound grows by q per stage, 11q after ten stages), and once in
+//     the inverse transform (where sums double per stage).
+// Why [0, q]: x*wp/2^32 = x*w/q + d with |d| < 2^19 * 0.5 / 2^32 = 2^-14 < 1/q, and the fractional
+// part of x*w/q is a multiple of 1/q, so the floor is exact except when x*w/q is an integer and
+// d < 0, which yields q instead of 0.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,65 +23,54 @@
 namespace fa {
 
 constexpr uint32_t Q = 12289u;
-constexpr uint32_t Q256 = Q * 256u;
-constexpr uint32_t ONE_WP = 1365u;  // floor(2^24 / q): Shoup companion of w = 1
-constexpr uint32_t SHOUP_SLACK = 48u;  // shoup() output <= 256*(q + 48) for x < 2^16
+constexpr int32_t QI = 12289;
+constexpr int32_t RQ32 = 349496;  // round(2^32 / q): Shoup companion of w = 1
 
 struct Tw {
-  uint32_t w;   // twiddle, canonical
-  uint32_t wp;  // floor(w * 2^24 / q)
+  int32_t w;   // twiddle, centred in (-q/2, q/2)
+  int32_t wp;  // round(w * 2^32 / q)
 };
 
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 
-__device__ __forceinline__ uint32_t mulhi24(uint32_t a, uint32_t b)
+// a * b + c with a, b signed 24-bit: one v_mad_i32_i24 (the backend fuses mul24 + add).
+__device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
+
+// |x| < 2^19  ->  (x * w) mod q as a value in [0, q].
+__device__ __forceinline__ int32_t shoup(int32_t x, int32_t w, int32_t wp)
 {
-  return (uint32_t)(((uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu)) >> 32);
+  const int32_t qh = __mulhi(x, wp);
+  return mad_i24(qh, -QI, __mul24(x, w));
 }
 
-// a * b + c with a, b signed 24-bit: hipcc lowers "c - a*Q256" to a quarter-rate v_mul_lo_u32,
-// so the instruction is named explicitly. b must be wave-uniform (SGPR operand).
-__device__ __forceinline__ uint32_t mad_i24(uint32_t a, int32_t b, uint32_t c)
+// |x| < 2^22  ->  x mod q as a value in [0, q] (the companion of w = 1 is off by only 0.04, so the
+// range is wider than shoup's). The instruction is named because hipcc otherwise picks the 64-bit
+// v_mad_u64_u32 here; the multiplier must be wave-uniform (SGPR operand).
+__device__ __forceinline__ int32_t reduce(int32_t x)
 {
-  uint32_t r;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  const int32_t qh = __mulhi(x, RQ32);
+  int32_t r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(qh), "s"(-QI), "v"(x));
   return r;
 }
 
-// X scaled (< 2^24). Returns 256 * ((w * x) mod q + e*q), e in {0, 1}, value <= 256*(q + 48).
-__device__ __forceinline__ uint32_t shoup(uint32_t X, uint32_t w, uint32_t wp)
-{
-  const uint32_t qh = mulhi24(X, wp);
-  return mad_i24(qh, -(int32_t)Q256, mul24(X, w));
-}
-
-// Full lazy reduction: X scaled < 2^24  ->  <= 256*(q + 11).
-__device__ __forceinline__ uint32_t reduce(uint32_t X)
-{
-  const uint32_t qh = mulhi24(X, ONE_WP);
-  return mad_i24(qh, -(int32_t)Q256, X);
-}
-
-// Conditional subtract: X < 2*M  ->  X mod-ish M (unsigned min trick, 2 instructions).
+// Conditional subtract: X < 2*M  ->  X mod M (unsigned min trick, 2 instructions).
 __device__ __forceinline__ uint32_t csub(uint32_t X, uint32_t M) { return min(X, X - M); }
-
-// Plain (unscaled) helpers ------------------------------------------------------------------
 
 // v < 2^17  ->  v mod q, canonical. Barrett with R = floor(2^28/q) = 21843 (ff.hpp:23).
 __device__ __forceinline__ uint32_t mod_q_17(uint32_t v)
 {
   const uint32_t qh = mul24(v, 21843u) >> 28;
-  const uint32_t r = mad_i24(qh, -(int32_t)Q, v);  // [0, 2q)
+  const uint32_t r = (uint32_t)mad_i24((int32_t)qh, -QI, (int32_t)v);  // [0, 2q)
   return csub(r, Q);
 }
 
-// a, b < 2^16 unscaled -> 256 * (a*b mod q), canonical. One quarter-rate multiply
-// (v_mul_hi_u32) per element; used only for the N pointwise products of a verify.
-__device__ __forceinline__ uint32_t mulmod_scaled(uint32_t a, uint32_t b)
+// a, b in [0, q] -> (a*b) mod q, canonical (polynomial.hpp:99-110, one element).
+__device__ __forceinline__ int32_t mulmod(int32_t a, int32_t b)
 {
-  const uint32_t p = mul24(a, b);
-  const uint32_t qh = __umulhi(p, 349496u);  // floor(2^32 / q)
-  return csub(mad_i24(qh, -(int32_t)Q, p), Q) << 8;
+  const uint32_t p = mul24((uint32_t)a, (uint32_t)b);                   // <= q^2 < 2^28
+  const uint32_t qh = __umulhi(p, 349496u);                            // floor(p/q) or one less
+  return (int32_t)csub((uint32_t)mad_i24((int32_t)qh, -QI, (int32_t)p), Q);
 }
 
 }  // namespace fa
