@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfalcon_amd.so")
+LIB_PATH = os.environ.get("FALCON_AMD_LIB") or os.path.join(_HERE, "libfalcon_amd.so")  # override: A/B builds only
 
 NORM_EXACT64, NORM_WRAP32 = 0, 1
 ST_OK, ST_BAD_PK_HEADER, ST_BAD_SIG_HEADER, ST_BAD_ENCODING, ST_NORM_TOO_LARGE = range(5)

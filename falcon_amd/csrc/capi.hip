@@ -189,7 +189,7 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   if (slots == 0) return 0;
   int rc = ctx->hraw.reserve((size_t)slots * nblk * 136);
   if (rc) return rc;
-  if ((rc = ctx->s2.reserve((size_t)slots * G::N * 2))) return rc;
+  if ((rc = ctx->s2.reserve(s2_tile_elems<LOGN>(slots) * 2))) return rc;
   if ((rc = ctx->sqn.reserve((size_t)slots * 4))) return rc;
   if ((rc = ctx->st2.reserve((size_t)slots))) return rc;
 

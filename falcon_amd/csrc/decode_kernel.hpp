@@ -12,7 +12,7 @@
 // Bits at or beyond the end of the signature read as 0 (the reference over-reads up to two
 // bytes there; no outcome depends on them, DESIGN.md "decoder over-read").
 //
-// Output per item: s2 lifted to [0, q) as u16 in natural order (the lift of
+// Output per item: s2 lifted to [0, q) as u16 in the tiled layout of s2_tile_offset below (the lift of
 // verification.hpp:36-39), the partial squared norm sum s2[i]^2, and a status byte.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,6 +26,18 @@ enum : uint8_t { ST_OK = 0, ST_BAD_PK_HEADER = 1, ST_BAD_SIG_HEADER = 2, ST_BAD_
                  ST_HASH_UNDERFLOW = 5 /* internal: needs more squeeze blocks */ };
 
 constexpr int DECODE_WG = 256;
+
+// Layout of the s2 workspace (internal to the pipeline, written by the decoders and read by the
+// verify kernel): tiles of 64 slots x 32 coefficients, s2t[slot / 64][i / 32][slot % 64][i % 32] (u16).
+// A wave of the fast decoder (64 consecutive slots) thus emits one contiguous 4 KiB tile per chunk of 32
+// coefficients -- full cache lines -- instead of 64-byte pieces scattered at row stride.
+template <int LOGN>
+__host__ __device__ __forceinline__ size_t s2_tile_offset(uint32_t slot, uint32_t i)
+{
+  return (((size_t)(slot >> 6) * ((1u << LOGN) / 32u) + (i >> 5)) * 64u + (slot & 63u)) * 32u + (i & 31u);
+}
+template <int LOGN>
+__host__ __device__ __forceinline__ size_t s2_tile_elems(size_t slots) { return ((slots + 63u) / 64u * 64u) << LOGN; }
 
 // MSB-first bit reader over the signature body (bytes 41..siglen-1), fed by aligned dwords.
 struct BitReader {
@@ -81,8 +93,8 @@ struct BitReader {
   }
 };
 
-// Generic decoder (every rule, including the k >= 8 windows). sig rows -> s2 (u16, lifted, natural
-// order, row stride n), sqn[o] = sum s2^2, st[o]. idx (nullable) maps slot -> item; outputs go to
+// Generic decoder (every rule, including the k >= 8 windows). sig rows -> s2 (u16, lifted, tiled
+// layout), sqn[o] = sum s2^2, st[o]. idx (nullable) maps slot -> item; outputs go to
 // index o = slot, or o = item when `scatter` (the fix-up pass behind decode_fast_kernel). The number
 // of slots is min(count, *dcount) when dcount is given (a device-side list length).
 template <int LOGN>
@@ -101,7 +113,6 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
   const uint32_t item = idx ? idx[slot] : slot;
   if (scatter) slot = item;
   const uint8_t* row = sig + (size_t)item * SIGLEN;
-  uint16_t* out = s2 + (size_t)slot * N;
 
   if (row[0] != (uint8_t)(0x30 | LOGN)) {  // decoding.hpp:376-382
     st[slot] = ST_BAD_SIG_HEADER;
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
       failed = true;
       break;
     }
-    out[i] = (uint16_t)(sign ? Q - mag : mag);
+    s2[s2_tile_offset<LOGN>(slot, (uint32_t)i)] = (uint16_t)(sign ? Q - mag : mag);
     norm += mag * mag;
     i++;
   }
@@ -166,18 +177,30 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast path: one signature per lane, but all memory traffic is wave-cooperative.
-//   * input: each lane owns a 128-byte ring in LDS that the whole wave refills with aligned 16-byte
-//     global loads (8 lanes per row), byte-swapped on the way in so a lane pulls MSB-first dwords;
-//   * output: 32 coefficients per lane are staged in LDS and written out as 64-byte row segments.
-// Only the common rule (k < 8 zeros in the unary part, 9..16 bits per coefficient) is handled here:
-// a lane that meets k == 8 stops and queues its item for decode_kernel (scatter mode), which
-// implements the window-skipping rule. Everything else (header, "-0", end-of-stream and trailing-zero
-// rules) is decided here exactly as in decode_kernel.
+// Fast path: one signature per lane, no bit buffer and no per-coefficient control flow.
+//   * Each lane owns a 128-byte ring in LDS holding the next 32 big-endian dwords of its row. A
+//     coefficient is decoded from ONE aligned ds_read2_b32 (the dword its code starts in and the next)
+//     and a 64-bit shift; an unaligned ds_read_b32 would save an instruction but stalls the LDS for the
+//     whole wave (SQ_LDS_UNALIGNED_STALL). The cursor is a bit position, so there is no refill branch;
+//     codes are 9..16 bits, hence a chunk of 32 coefficients consumes at most 64 bytes. Stream dword n
+//     sits at ring index 32 - (n & 31) (descending, so the pair comes back in {low, high} register
+//     order); index 0 mirrors index 32 for the pair that straddles the wrap.
+//   * The ring is refilled in 16-byte pieces by the lane itself: the pieces the NEXT chunk can need
+//     are requested at the start of a chunk (at most 4, into registers) and stored to LDS at its end,
+//     so the HBM latency hides behind the chunk's arithmetic and every piece is fetched exactly once.
+//   * Nothing is predicated per coefficient: a lane keeps decoding whatever bits it sees and the
+//     verdict is derived afterwards from three running values -- the largest unary count (8 = the
+//     k >= 8 window rule, which only decode_kernel implements: the item is queued for it), the largest
+//     output value (q = "-0"), and the final cursor (at or past the last bit = rejected,
+//     decoding.hpp:340). Bits past the end of a row are whatever follows in memory; every path that
+//     looks at them ends in one of those three outcomes, so they never influence a result.
+//   * Output: the 64 x 32 coefficients of a chunk form one contiguous 4 KiB tile (s2_tile_offset); it is
+//     turned through LDS and leaves as four fully coalesced 1 KiB stores.
 // ------------------------------------------------------------------------------------------------
-constexpr int DF_CH = 32;       // coefficients per chunk
-constexpr int DF_RING = 33;     // dwords per lane: 32 of ring + 1 of padding (bank-conflict free)
-constexpr int DF_OUT = 17;      // dwords per lane: 32 u16 + padding
+constexpr int DF_CH = 32;        // coefficients per chunk
+constexpr int DF_RING_DW = 33;   // dwords per lane: mirror + 32 ring dwords (odd stride: conflict free)
+constexpr int DF_OUT = 20;       // dwords per lane of the output stage: 16 + 4 (keeps 16-byte alignment, spreads banks)
+constexpr uint32_t DF_AHEAD = 72;  // bytes beyond the cursor a chunk may touch: 64 consumed + one dword pair
 
 template <int LOGN>
 __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restrict__ sig, uint32_t count,
@@ -188,161 +211,147 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   constexpr int N = 1 << LOGN;
   constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
   constexpr uint32_t BODY = SIGLEN - 41;
-  __shared__ uint32_t ring[64 * DF_RING];
-  __shared__ uint32_t outb[64 * DF_OUT];
-  __shared__ uint32_t s_wq[64], s_tq[64];  // per row: next piece to load, piece to load up to
+  __shared__ uint32_t ring[64 * DF_RING_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t outb[64 * DF_OUT];
 
   const uint32_t lane = threadIdx.x;
   const uint32_t slot0 = blockIdx.x * 64u;
   const uint32_t slot = slot0 + lane;
   const bool live = slot < count;
+  const uint32_t row = live ? slot : count - 1u;  // idle lanes shadow the last row and write nothing
 
-  // geometry of this lane's row, relative to the 16-byte aligned address `abase` below the body
-  const uintptr_t body = (uintptr_t)(sig + (size_t)(live ? slot : 0u) * SIGLEN + 41);
-  const uint32_t boff = (uint32_t)(body & 15u);
-  const uint32_t end_bits = 8u * (boff + BODY);  // first bit past the signature
+  // geometry of this lane's row, relative to the 16-byte aligned address `abase` at or below the body
+  const uint8_t* body = sig + (size_t)row * SIGLEN + 41;
+  const uint32_t boff = (uint32_t)((uintptr_t)body & 15u);
+  const uint4* abase = (const uint4*)(body - boff);  // derived from `sig` by pointer arithmetic only: global loads, not flat
+  const uint32_t end_bits = 8u * (boff + BODY);        // first bit past the signature
+  const uint32_t plast = (boff + BODY - 1u) >> 4;      // last piece holding a byte of the row (never read past it)
+  uint32_t* myring = ring + lane * DF_RING_DW;
 
-  // the same for the row this lane helps to load: row (lane>>3) + 8t, piece lane&7
-  // Row geometry of the 8 rows this lane helps to load is loop-invariant: keep it in registers.
-  uintptr_t rbase[8];
-  uint32_t rlast[8];  // last piece that holds a byte of the row
-#pragma unroll
-  for (int t = 0; t < 8; t++) {
-    const uint32_t rs = min(slot0 + (lane >> 3) + 8u * t, count - 1u);
-    const uintptr_t rbody = (uintptr_t)(sig + (size_t)rs * SIGLEN + 41);
-    rbase[t] = rbody & ~(uintptr_t)15;
-    rlast[t] = ((uint32_t)(rbody & 15u) + BODY - 1u) >> 4;
-  }
-  auto load_pieces = [&]() {
-    uint4 v[8];
-    uint32_t q[8];
-    bool want[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {  // all eight loads in flight before the first LDS write
-      const uint32_t r = (lane >> 3) + 8u * t;
-      q[t] = s_wq[r] + (lane & 7u);
-      want[t] = q[t] < s_tq[r] && q[t] <= rlast[t];
-      v[t] = *(const uint4*)(rbase[t] + 16u * (uintptr_t)min(q[t], rlast[t]));
-    }
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-      if (want[t]) {
-        uint32_t* dst = ring + ((lane >> 3) + 8u * t) * DF_RING + (q[t] & 7u) * 4u;
-        dst[0] = __builtin_bswap32(v[t].x);
-        dst[1] = __builtin_bswap32(v[t].y);
-        dst[2] = __builtin_bswap32(v[t].z);
-        dst[3] = __builtin_bswap32(v[t].w);
-      }
-    }
+  auto put_piece = [&](uint32_t piece, const uint4& v) {  // stream dwords 4*piece .. 4*piece+3
+    uint32_t* dst = myring + 32u - (piece & 7u) * 4u;
+    dst[0] = __builtin_bswap32(v.x);
+    dst[-1] = __builtin_bswap32(v.y);
+    dst[-2] = __builtin_bswap32(v.z);
+    dst[-3] = __builtin_bswap32(v.w);
+    if ((piece & 7u) == 0u) myring[0] = __builtin_bswap32(v.x);  // mirror of index 32
   };
-  auto wave_sync = [&]() {
+  // the stream from bit p (relative to abase) on, MSB first, in the top 64 - (p & 31) bits
+  auto window64 = [&](uint32_t p) -> uint64_t {
+    const uint32_t* src = myring + 31u - ((p >> 5) & 31u);  // {next dword, this dword}
+    return (((uint64_t)src[1] << 32) | src[0]) << (p & 31u);
+  };
+  auto window = [&](uint32_t p) -> uint32_t { return (uint32_t)(window64(p) >> 32); };
+
+  uint32_t pos = 8u * boff;  // bit cursor relative to abase; body bit 0 == absolute bit 328 (decoding.hpp:276-277)
+  uint32_t ld = 0;           // pieces [0, ld) have been put into the ring
+  {  // prologue: enough for the first chunk
+    uint4 v[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) v[t] = abase[min((uint32_t)t, plast)];
+#pragma unroll
+    for (int t = 0; t < 6; t++) put_piece((uint32_t)t, v[t]);
+    ld = 6;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  uint32_t norm = 0u, maxk = 0u, maxv = 0u;
+
+  // pieces the chunk AFTER the one starting at the current cursor may need: everything below byte
+  // (cursor + 64) + DF_AHEAD. Requested into registers now, put into the ring one chunk later.
+  uint32_t want = 0;
+  uint4 nv[4];
+  auto request = [&]() {
+    want = min((((pos >> 3) + 64u + DF_AHEAD + 15u) >> 4), plast + 1u);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (ld + t < want) nv[t] = abase[ld + t];
+  };
+  request();
+
+  for (int ch = 0; ch < N / DF_CH; ch++) {
+    // Two coefficients per LDS read: after the alignment shift at least 33 bits of the pair are valid, a
+    // code is at most 16 bits long and its decoding looks at 16 bits, so the second code still sees only
+    // valid bits. This halves the LDS round trips on the serial cursor chain.
+    uint32_t packed[DF_CH / 2];
+#pragma unroll
+    for (int j = 0; j < DF_CH; j += 2) {
+      uint64_t win = window64(pos);
+      uint32_t val[2], len[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t top = (uint32_t)(win >> 32);  // code starts at bit 31
+        const uint32_t k = (uint32_t)__builtin_clz((top << 8) | 0x00800000u);  // zeros in the 8-bit unary window
+        const uint32_t mag = ((top >> 24) & 0x7fu) + (k << 7);
+        const uint32_t neg = (uint32_t)((int32_t)top >> 31);
+        val[h] = (mag ^ neg) + (neg & (Q + 1u));     // sign ? q - mag : mag (verification.hpp:36-39)
+        len[h] = 9u + k;
+        norm += mul24(mag, mag);
+        maxk = max(maxk, k);
+        maxv = max(maxv, val[h]);
+        if (h == 0) win <<= len[0];
+      }
+      pos += len[0] + len[1];
+      packed[j >> 1] = val[0] | (val[1] << 16);
+    }
+    // The pieces requested one chunk ago have arrived behind the arithmetic; by now the cursor has moved
+    // on by at least 36 bytes, so the at most 8 live pieces [cursor >> 7, want) fit the ring.
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (ld + t < want) put_piece(ld + t, nv[t]);
+    ld = max(ld, want);
+    request();  // for the chunk after next; issued before the stores below so that it waits for nothing
+    // The wave's 4 KiB tile (s2_tile_offset: [block][ch][row][32]) goes out as four 1 KiB stores, 16
+    // contiguous bytes per lane: lane L holds row L's 64 bytes, so the tile is turned through LDS first
+    // (a store of 16 bytes per lane at a 64-byte lane stride is 64 separate L2 requests per instruction).
+    {
+      uint4* mine = (uint4*)(outb + lane * DF_OUT);
+#pragma unroll
+      for (int t = 0; t < 4; t++) mine[t] = make_uint4(packed[4 * t], packed[4 * t + 1], packed[4 * t + 2], packed[4 * t + 3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint4* tile = (uint4*)(s2 + s2_tile_offset<LOGN>(slot0, (uint32_t)ch * DF_CH));
+#ifndef FA_DEC_NOSTORE
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const uint32_t r = 16u * t + (lane >> 2);  // row, piece lane & 3
+        if (slot0 + r < count) tile[64u * t + lane] = *(const uint4*)(outb + r * DF_OUT + (lane & 3u) * 4u);
+      }
+#endif
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-
-  uint32_t rd = boff & ~3u;  // byte offset (from abase) of the next dword to pull
-  s_wq[lane] = 0u;
-  s_tq[lane] = 8u;
-  wave_sync();
-  load_pieces();
-  s_wq[lane] = 8u;
-  wave_sync();
-
-  const uint32_t* myring = ring + lane * DF_RING;
-  auto pull = [&]() -> uint32_t {
-    const uint32_t w = myring[(rd >> 2) & 31u];
-    rd += 4u;
-    return w;
-  };
-  uint64_t buf = (uint64_t)pull() << (32u + 8u * (boff & 3u));
-  int32_t nbits = 32 - 8 * (int32_t)(boff & 3u);
-  uint32_t pos = 8u * boff;  // bit position relative to abase; body bit 0 == absolute bit 328
-  int32_t i = 0;
-  uint32_t norm = 0u;
-  bool failed = false, quirk = false;
-  const bool hdr_ok = live && sig[(size_t)slot * SIGLEN] == (uint8_t)(0x30 | LOGN);
-  bool alive = hdr_ok;
-  uint16_t* orow = s2 + (size_t)slot0 * N;
-
-  for (int ch = 0; ch < N / DF_CH; ch++) {
-    uint32_t prev = 0u;
-#pragma unroll 2
-    for (int j = 0; j < DF_CH; j++) {
-      if (alive && nbits <= 32) {
-        buf |= (uint64_t)pull() << (32 - nbits);
-        nbits += 32;
-      }
-      alive = alive && pos < end_bits;  // decoding.hpp:281
-      const uint32_t top = (uint32_t)(buf >> 32);
-      const uint32_t sign = top >> 31;
-      const uint32_t k = (uint32_t)__builtin_clz((top << 8) | 0x00800000u);
-      const uint32_t mag = ((top >> 24) & 0x7fu) + (k << 7);
-      if (alive) {
-        if (k == 8u) {
-          quirk = true;
-          alive = false;
-        } else if (sign && mag == 0u) {  // decoding.hpp:327-330
-          failed = true;
-          alive = false;
-        } else {
-          buf <<= (9u + k);
-          nbits -= (int32_t)(9u + k);
-          pos += 9u + k;
-          norm += mag * mag;
-          i++;
-        }
-      }
-      const uint32_t val = sign ? Q - mag : mag;
-      if (j & 1) outb[lane * DF_OUT + (j >> 1)] = prev | (val << 16);
-      prev = val;
-    }
-    wave_sync();
-    // flush 64 rows x 64 bytes; refill every ring up to 8 pieces beyond the reader
-    if (slot0 + 64u <= count) {  // wave-uniform: full tile, no per-row guard
-#pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const uint32_t e = t * 64u + lane, r = e >> 4, dw = e & 15u;
-        ((uint32_t*)(orow + (size_t)r * N + ch * DF_CH))[dw] = outb[r * DF_OUT + dw];
-      }
-    } else {
-      for (int t = 0; t < 16; t++) {
-        const uint32_t e = t * 64u + lane, r = e >> 4, dw = e & 15u;
-        if (slot0 + r < count) ((uint32_t*)(orow + (size_t)r * N + ch * DF_CH))[dw] = outb[r * DF_OUT + dw];
-      }
-    }
-    s_tq[lane] = (rd >> 4) + 8u;
-    wave_sync();
-    load_pieces();
-    s_wq[lane] = s_tq[lane];
-    wave_sync();
   }
 
   if (!live) return;
-  if (!hdr_ok) {  // decoding.hpp:376-382
+  if (sig[(size_t)slot * SIGLEN] != (uint8_t)(0x30 | LOGN)) {  // decoding.hpp:376-382
     st[slot] = ST_BAD_SIG_HEADER;
     sqn[slot] = 0u;
     return;
   }
-  if (quirk) {
+  // Trailing bits (decoding.hpp:342-357) are checked from the ring, which holds the row up to piece ld.
+  const bool past_end = pos >= end_bits;                              // decoding.hpp:340
+  const bool tail_missing = !past_end && end_bits > 128u * ld;        // tail longer than the ring holds: rare
+  if (maxk == 8u || tail_missing) {                                   // needs the generic decoder
     st[slot] = ST_BAD_ENCODING;  // overwritten by the fix-up pass
     sqn[slot] = 0u;
     slow_list[atomicAdd(slow_count, 1u)] = slot;
     return;
   }
-  failed |= (pos >= end_bits) | (i < N);  // decoding.hpp:340
-  if (!failed) {  // decoding.hpp:342-357
-    while (pos < end_bits) {
-      if (nbits <= 32) {
-        buf |= (uint64_t)pull() << (32 - nbits);
-        nbits += 32;
-      }
-      const uint32_t e = min(32u, end_bits - pos);
-      failed |= ((uint32_t)(buf >> 32) >> (32u - e)) != 0u;
-      buf <<= e;
-      nbits -= (int32_t)e;
-      pos += e;
+  bool failed = past_end || maxv == Q;                                // "-0": decoding.hpp:327-330
+  if (!failed) {
+    uint32_t acc = 0u;
+    uint32_t p = pos;
+    while (p < end_bits) {
+      const uint32_t e = min(32u, end_bits - p);
+      acc |= window(p) >> (32u - e);
+      p += e;
     }
+    failed = acc != 0u;
   }
   st[slot] = failed ? ST_BAD_ENCODING : ST_OK;
   sqn[slot] = norm;

@@ -259,7 +259,7 @@ template <int LOGN>
 struct VerifyArgs {
   const uint8_t* pk;        // [items][PKLEN]
   const uint64_t* hraw;     // [slots][nblk*17]
-  const uint16_t* s2;       // [slots][N] lifted, natural order (decode kernels)
+  const uint16_t* s2;       // lifted s2 in the tiled layout of s2_tile_offset (decode kernels)
   const uint32_t* sqn;      // [slots]
   const uint8_t* st2;       // [slots]
   const uint32_t* idx;      // slot -> item, nullable
@@ -302,9 +302,9 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
     const uint32_t d = t * 64u + lane;
     r.hw[t] = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are always rejected
   }
-  const uint16_t* s2row = A.s2 + (size_t)slot * G::N;
+  const uint16_t* s2row = A.s2 + s2_tile_offset<LOGN>(slot, 0u);  // tiled: chunk stride 64*32, see decode_kernel.hpp
 #pragma unroll
-  for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[idxA<LOGN>(lane, m)];
+  for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];  // i = 64 m + lane
   const uint8_t* pkrow = A.pk + (size_t)r.item * G::PKLEN;
   r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
   const uint32_t* pbase = (const uint32_t*)(pkrow - r.pal);
