@@ -185,9 +185,9 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
 //     codes are 9..16 bits, hence a chunk of 32 coefficients consumes at most 64 bytes. Stream dword n
 //     sits at ring index 32 - (n & 31) (descending, so the pair comes back in {low, high} register
 //     order); index 0 mirrors index 32 for the pair that straddles the wrap.
-//   * The ring is refilled in 16-byte pieces by the lane itself: the pieces the NEXT chunk can need
-//     are requested at the start of a chunk (at most 4, into registers) and stored to LDS at its end,
-//     so the HBM latency hides behind the chunk's arithmetic and every piece is fetched exactly once.
+//   * The ring is refilled in 16-byte pieces: the pieces the chunk after next can need (at most 4 per
+//     row) are requested at the end of a chunk, four lanes per row, into registers, and stored to LDS one
+//     chunk later, so the HBM latency hides behind a chunk's arithmetic and every piece is fetched once.
 //   * Nothing is predicated per coefficient: a lane keeps decoding whatever bits it sees and the
 //     verdict is derived afterwards from three running values -- the largest unary count (8 = the
 //     k >= 8 window rule, which only decode_kernel implements: the item is queued for it), the largest
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   constexpr uint32_t BODY = SIGLEN - 41;
   __shared__ uint32_t ring[64 * DF_RING_DW];
   __shared__ __attribute__((aligned(16))) uint32_t outb[64 * DF_OUT];
+  __shared__ uint32_t s_ld[64], s_want[64];  // per row: pieces in the ring, pieces wanted
 
   const uint32_t lane = threadIdx.x;
   const uint32_t slot0 = blockIdx.x * 64u;
@@ -228,13 +229,13 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   const uint32_t plast = (boff + BODY - 1u) >> 4;      // last piece holding a byte of the row (never read past it)
   uint32_t* myring = ring + lane * DF_RING_DW;
 
-  auto put_piece = [&](uint32_t piece, const uint4& v) {  // stream dwords 4*piece .. 4*piece+3
-    uint32_t* dst = myring + 32u - (piece & 7u) * 4u;
+  auto put_piece = [&](uint32_t* rowring, uint32_t piece, const uint4& v) {  // stream dwords 4*piece .. 4*piece+3
+    uint32_t* dst = rowring + 32u - (piece & 7u) * 4u;
     dst[0] = __builtin_bswap32(v.x);
     dst[-1] = __builtin_bswap32(v.y);
     dst[-2] = __builtin_bswap32(v.z);
     dst[-3] = __builtin_bswap32(v.w);
-    if ((piece & 7u) == 0u) myring[0] = __builtin_bswap32(v.x);  // mirror of index 32
+    if ((piece & 7u) == 0u) rowring[0] = __builtin_bswap32(v.x);  // mirror of index 32
   };
   // the stream from bit p (relative to abase) on, MSB first, in the top 64 - (p & 31) bits
   auto window64 = [&](uint32_t p) -> uint64_t {
@@ -245,12 +246,17 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
 
   uint32_t pos = 8u * boff;  // bit cursor relative to abase; body bit 0 == absolute bit 328 (decoding.hpp:276-277)
   uint32_t ld = 0;           // pieces [0, ld) have been put into the ring
-  {  // prologue: enough for the first chunk
-    uint4 v[6];
+  {  // prologue: pieces 0..5 of every row (enough for the first chunk), eight lanes per row
+    uint4 v[8];
 #pragma unroll
-    for (int t = 0; t < 6; t++) v[t] = abase[min((uint32_t)t, plast)];
+    for (int t = 0; t < 8; t++) {
+      const uint8_t* b = sig + (size_t)min(slot0 + 8u * t + (lane >> 3), count - 1u) * SIGLEN + 41;
+      const uint32_t last = ((uint32_t)((uintptr_t)b & 15u) + BODY - 1u) >> 4;
+      if ((lane & 7u) < 6u) v[t] = ((const uint4*)(b - ((uintptr_t)b & 15u)))[min(lane & 7u, last)];
+    }
 #pragma unroll
-    for (int t = 0; t < 6; t++) put_piece((uint32_t)t, v[t]);
+    for (int t = 0; t < 8; t++)
+      if ((lane & 7u) < 6u) put_piece(ring + (8u * t + (lane >> 3)) * DF_RING_DW, lane & 7u, v[t]);
     ld = 6;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -259,15 +265,34 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
 
   uint32_t norm = 0u, maxk = 0u, maxv = 0u;
 
-  // pieces the chunk AFTER the one starting at the current cursor may need: everything below byte
-  // (cursor + 64) + DF_AHEAD. Requested into registers now, put into the ring one chunk later.
+  // Refill. A row needs the pieces below byte (cursor + 64) + DF_AHEAD for the chunk AFTER the one that starts
+  // at the current cursor: at most 4 new ones. Rows publish [ld, want) in LDS and four neighbouring lanes
+  // fetch one row's pieces together (row 16 t + lane / 4, piece ld + lane % 4), so the up to 64 contiguous
+  // bytes of a row are one L2 request instead of four -- the kernel is bound by the number of outstanding
+  // requests, not by bytes. The data waits in registers and is put into the rings one chunk later.
+  const uint4* lbase[4];  // aligned base of the row this lane helps to load in round t
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const uint8_t* b = sig + (size_t)min(slot0 + 16u * t + (lane >> 2), count - 1u) * SIGLEN + 41;
+    lbase[t] = (const uint4*)(b - ((uintptr_t)b & 15u));
+  }
   uint32_t want = 0;
+  uint32_t lp[4];  // piece held in nv[t], ~0 = none
   uint4 nv[4];
   auto request = [&]() {
     want = min((((pos >> 3) + 64u + DF_AHEAD + 15u) >> 4), plast + 1u);
+    s_ld[lane] = ld;
+    s_want[lane] = want;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-      if (ld + t < want) nv[t] = abase[ld + t];
+    for (int t = 0; t < 4; t++) {
+      const uint32_t r = 16u * t + (lane >> 2);
+      const uint32_t p = s_ld[r] + (lane & 3u);
+      lp[t] = p < s_want[r] ? p : ~0u;
+      if (lp[t] != ~0u) nv[t] = lbase[t][p];
+    }
   };
   request();
 
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
     // on by at least 36 bytes, so the at most 8 live pieces [cursor >> 7, want) fit the ring.
 #pragma unroll
     for (int t = 0; t < 4; t++)
-      if (ld + t < want) put_piece(ld + t, nv[t]);
+      if (lp[t] != ~0u) put_piece(ring + (16u * t + (lane >> 2)) * DF_RING_DW, lp[t], nv[t]);
     ld = max(ld, want);
     request();  // for the chunk after next; issued before the stores below so that it waits for nothing
     // The wave's 4 KiB tile (s2_tile_offset: [block][ch][row][32]) goes out as four 1 KiB stores, 16
