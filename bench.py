@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--items", type=int, default=1 << 20, help="items per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="override FA_OPT_CHUNK_ITEMS")
     ap.add_argument("--cpu-sample", type=int, default=1 << 18)
+    ap.add_argument("--logn", type=int, default=9, choices=(9, 10),
+                    help="9 = Falcon-512 (the headline workload, BASELINE.json configs[2]); 10 = Falcon-1024 (A/B runs only)")
+    ap.add_argument("--malformed", type=int, default=0, help="permille of malformed items in the timed corpus (A/B runs only)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -83,9 +86,10 @@ def main():
     # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
     n_items = args.items
     t0 = time.time()
-    pk, msg, sig, _ = support.corpus().generate(9, n_items, seed=0xFA1C0512, first=rank * n_items, mlen=32,
-                                                threads=threads)
-    log(f"[rank {rank}] corpus: {n_items} Falcon-512 triples in {time.time() - t0:.1f}s ({threads} threads)")
+    logn = args.logn
+    pk, msg, sig, _ = support.corpus().generate(logn, n_items, seed=0xFA1C0512, first=rank * n_items, mlen=32,
+                                                malformed_permille=args.malformed, threads=threads)
+    log(f"[rank {rank}] corpus: {n_items} Falcon-{1 << logn} triples in {time.time() - t0:.1f}s ({threads} threads)")
     d_pk = torch.from_numpy(pk).to(dev)
     d_msg = torch.from_numpy(np.ascontiguousarray(msg)).to(dev)
     d_sig = torch.from_numpy(sig).to(dev)
@@ -93,7 +97,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ctx.verify_many_dev(9, n_items, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
+        ctx.verify_many_dev(logn, n_items, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
                             d_acc.data_ptr(), stream=stream)
 
     for _ in range(args.warmup):
@@ -125,12 +129,12 @@ def main():
     total_items = n_items * world * args.steps
     value = total_items / elapsed
     result = {
-        "metric": "Falcon-512 verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
+        "metric": f"Falcon-{1 << logn} verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (mod q = 12289), u64 Keccak lanes",
         "data": "synthetic",
-        "config": {"workload": "Falcon-512 batched verify, 2^20 distinct keys/signatures per GPU, 32-byte messages, "
-                               "device-resident (BASELINE.json configs[2])",
+        "config": {"workload": f"Falcon-{1 << logn} batched verify, {n_items} distinct keys/signatures per GPU, 32-byte messages, "
+                               f"device-resident (BASELINE.json configs[{logn - 7}])" + (f", {args.malformed} permille malformed" if args.malformed else ""),
                    "items_per_gpu": n_items, "parallelism": f"items sharded over {world} GPU(s), no collective"},
         "accepted_fraction": accepted / (n_items * world),
     }
@@ -170,11 +174,11 @@ def main():
         ns = min(args.cpu_sample, n_items)
         orc = support.oracle()
         t0 = time.perf_counter()
-        flags, _ = orc.verify_many(9, pk[:ns], msg[:ns], sig[:ns], threads=threads)
+        flags, _ = orc.verify_many(logn, pk[:ns], msg[:ns], sig[:ns], threads=threads)
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
         n1 = min(8192, ns)
-        orc.verify_many(9, pk[:n1], msg[:n1], sig[:n1], threads=1)
+        orc.verify_many(logn, pk[:n1], msg[:n1], sig[:n1], threads=1)
         dt1 = time.perf_counter() - t1
         gpu_flags = d_acc[:ns].cpu().numpy()
         result["cpu_baseline"] = {

@@ -495,10 +495,11 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
 int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off,
                    uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
 {
-  if (!ctx) return FA_E_ARG;
+  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
   if (logn != 9 && logn != 10) return FA_E_LOGN;
   if (count == 0) return 0;
   if (!pk || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  if (count > 0xFFFFFFFFull) return FA_E_ARG;
   Guard g(ctx->device);
   if (g.err) return g.err;
   const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);

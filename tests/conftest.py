@@ -25,5 +25,14 @@ def corpus():
 
 @pytest.fixture(scope="session")
 def ctx():
+    # torch ships its own copy of the HIP runtime: when a test uses both, torch has to load (and
+    # initialise) first, or its later initialisation finds the runtime of /opt/rocm already in place
+    # and reports "No HIP GPUs are available".
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import falcon_amd
     return falcon_amd.default_context(0)

@@ -63,3 +63,83 @@ def test_malformed_classes(ctx, oracle, corpus, logn, kind):
     _compare_debug(logn, flags, odbg, acc, gdbg)
     accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)  # wrap32 == the g++-built reference
     np.testing.assert_array_equal(accw, (flags >> 1) & 1)
+
+
+# ---- edge cases: ragged and long messages, empty and tiny batches, chunking, the re-hash pass ----
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_message_lengths_and_ragged_offsets(ctx, oracle, corpus, logn):
+    """mlen 0..1024 covers single- and multi-block absorbs (tests/test_signing.cpp:18-19 signs mlen 1..1024);
+    the last batch mixes all lengths through the offset-indexed form."""
+    lens = [0, 1, 32, 95, 96, 135, 136, 137, 271, 1024]
+    pks, sigs, msgs = [], [], []
+    for j, mlen in enumerate(lens):
+        pk, msg, sig, _ = corpus.generate(logn, 33, seed=40 + j, mlen=mlen, malformed_permille=200)
+        flags, _ = oracle.verify_many(logn, pk, msg, sig, threads=8)
+        acc = ctx.verify_many(logn, pk, msg, sig)
+        np.testing.assert_array_equal(acc, flags & 1, err_msg=f"mlen={mlen}")
+        pks.append(pk); sigs.append(sig); msgs.extend(list(msg))
+    pk, sig = np.concatenate(pks), np.concatenate(sigs)
+    off = np.concatenate([[0], np.cumsum([m.size for m in msgs])]).astype(np.uint64)
+    flat = np.concatenate([m for m in msgs if m.size] or [np.zeros(0, np.uint8)])
+    flags, odbg = oracle.verify_many(logn, pk, flat, sig, msg_off=off, debug=True, threads=8)
+    acc, gdbg = ctx.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
+    _compare_debug(logn, flags, odbg, acc, gdbg)
+
+
+def test_empty_and_tiny_batches(ctx, oracle, corpus):
+    pk, msg, sig, _ = corpus.generate(9, 3, seed=9)
+    assert ctx.verify_many(9, pk[:0], msg[:0], sig[:0]).shape == (0,)
+    for n in (1, 2, 3):
+        np.testing.assert_array_equal(ctx.verify_many(9, pk[:n], msg[:n], sig[:n]), np.ones(n, np.uint8))
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_chunked_passes_and_rehash(oracle, corpus, logn):
+    """A private context with 64-item passes and too few squeeze blocks up front: every pass boundary and the
+    re-hash pass (items whose rejection sampling runs out of blocks) are exercised."""
+    from falcon_amd import capi
+    c = capi.Context(0)
+    try:
+        c.set_option(capi.OPT_CHUNK_ITEMS, 64)
+        c.set_option(capi.OPT_HASH_BLOCKS_512 if logn == 9 else capi.OPT_HASH_BLOCKS_1024, 8 if logn == 9 else 16)
+        pk, msg, sig, _ = corpus.generate(logn, 1000, seed=77, malformed_permille=300)
+        flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
+        acc, gdbg = c.verify_many(logn, pk, msg, sig, debug=True)
+        _compare_debug(logn, flags, odbg, acc, gdbg)
+        prof = c.get_profile()
+        need_more = int((odbg["hash_blocks"] > (8 if logn == 9 else 16)).sum())
+        assert need_more > 0 and prof["retried_items"] >= need_more
+    finally:
+        c.close()
+
+
+def test_mixed_batch(ctx, oracle, corpus):
+    """fa_verify_mixed: Falcon-512 and Falcon-1024 items interleaved, split by N on the host."""
+    rng = np.random.default_rng(3)
+    p9 = corpus.generate(9, 150, seed=1, malformed_permille=300)
+    p10 = corpus.generate(10, 150, seed=2, malformed_permille=300)
+    want9 = oracle.verify_many(9, *p9[:3], threads=8)[0] & 1
+    want10 = oracle.verify_many(10, *p10[:3], threads=8)[0] & 1
+    order = rng.permutation(300)
+    logn, pk, sig, msg, want = [], [], [], [], []
+    for o in order:
+        src, w, ln, i = (p9, want9, 9, o) if o < 150 else (p10, want10, 10, o - 150)
+        logn.append(ln); pk.append(src[0][i]); msg.append(src[1][i]); sig.append(src[2][i]); want.append(w[i])
+    cat = lambda xs: (np.concatenate(xs), np.concatenate([[0], np.cumsum([x.size for x in xs])]).astype(np.uint64))
+    (pkb, pko), (msgb, msgo), (sigb, sigo) = cat(pk), cat(msg), cat(sig)
+    acc = ctx.verify_mixed(np.array(logn, np.uint8), pkb, pko[:-1], msgb, msgo, sigb, sigo[:-1])
+    np.testing.assert_array_equal(acc, np.array(want, np.uint8))
+
+
+def test_argument_errors(ctx):
+    from falcon_amd import capi
+    lib = capi.load_library()
+    z = np.zeros(4096, np.uint8)
+    acc = np.zeros(4, np.uint8)
+    p = lambda a: a.ctypes.data
+    assert lib.fa_verify_many(ctx.handle, 8, 1, p(z), p(z), None, 32, p(z), 0, p(acc), None) == -2   # FA_E_LOGN
+    assert lib.fa_verify_many(ctx.handle, 9, 1, None, p(z), None, 32, p(z), 0, p(acc), None) == -1   # FA_E_ARG
+    assert lib.fa_verify_many(ctx.handle, 9, 1, p(z), p(z), None, 32, p(z), 7, p(acc), None) == -1   # bad policy
+    assert lib.fa_verify_many_dev(ctx.handle, 9, 1, 0x1001, 0x1000, None, 32, 0x1000, 0, 0x1000, None, None) == -3  # FA_E_ALIGN
+    assert lib.fa_set_option(ctx.handle, 99, 1) == -1
