@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--logn", type=int, default=9, choices=(9, 10),
                     help="9 = Falcon-512 (the headline workload, BASELINE.json configs[2]); 10 = Falcon-1024 (A/B runs only)")
     ap.add_argument("--malformed", type=int, default=0, help="permille of malformed items in the timed corpus (A/B runs only)")
-    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--overlap", type=int, default=-1, help="override FA_OPT_OVERLAP (A/B runs only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -80,8 +80,8 @@ def main():
     ctx = capi.Context(local_rank)
     if args.chunk:
         ctx.set_option(capi.OPT_CHUNK_ITEMS, args.chunk)
-    if args.no_overlap:
-        ctx.set_option(capi.OPT_OVERLAP, 0)
+    if args.overlap >= 0:
+        ctx.set_option(capi.OPT_OVERLAP, args.overlap)
 
     # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
     n_items = args.items

@@ -159,7 +159,7 @@ __device__ __forceinline__ void gs_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
 }
 
 template <int LOGN, int PHASE_FROM>  // 0: A->B, 1: B->C, 2: C->B, 3: B->A
-__device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
+__device__ __forceinline__ void transpose_out(const int32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
 {
   constexpr int R = Geo<LOGN>::R;
 #pragma unroll
@@ -169,7 +169,11 @@ __device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* 
     if constexpr (PHASE_FROM == 2) buf[padBC<LOGN>(idxC<LOGN>(lane, m))] = (uint32_t)x[m];
     if constexpr (PHASE_FROM == 3) buf[padAB<LOGN>(idxB<LOGN>(lane, m))] = (uint32_t)x[m];
   }
-  wave_lds_sync();
+}
+template <int LOGN, int PHASE_FROM>
+__device__ __forceinline__ void transpose_in(int32_t (&x)[Geo<LOGN>::R], const uint32_t* __restrict__ buf, uint32_t lane)
+{
+  constexpr int R = Geo<LOGN>::R;
 #pragma unroll
   for (int m = 0; m < R; m++) {
     if constexpr (PHASE_FROM == 0) x[m] = (int32_t)buf[padAB<LOGN>(idxB<LOGN>(lane, m))];
@@ -177,6 +181,13 @@ __device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* 
     if constexpr (PHASE_FROM == 2) x[m] = (int32_t)buf[padBC<LOGN>(idxB<LOGN>(lane, m))];
     if constexpr (PHASE_FROM == 3) x[m] = (int32_t)buf[padAB<LOGN>(idxA<LOGN>(lane, m))];
   }
+}
+template <int LOGN, int PHASE_FROM>
+__device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
+{
+  transpose_out<LOGN, PHASE_FROM>(x, buf, lane);
+  wave_lds_sync();
+  transpose_in<LOGN, PHASE_FROM>(x, buf, lane);
   wave_lds_sync();
 }
 
@@ -201,6 +212,34 @@ __device__ __forceinline__ void ntt_forward(int32_t (&x)[Geo<LOGN>::R], const Tw
   ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB);
   transpose<LOGN, 1>(x, buf, lane);
   ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane);
+}
+
+// Two independent forward transforms side by side (the s2 and h of one item, or a and b of one product):
+// stage for stage on both, each with its own transpose buffer, so one transform's LDS round trips and
+// dependent Shoup chains hide behind the other's arithmetic.
+template <int LOGN>
+__device__ __forceinline__ void ntt_forward2(int32_t (&x)[Geo<LOGN>::R], int32_t (&y)[Geo<LOGN>::R], const TwTabs& T,
+                                             uint32_t* __restrict__ bufx, uint32_t* __restrict__ bufy, uint32_t lane)
+{
+  using G = Geo<LOGN>;
+  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
+  transpose_out<LOGN, 0>(x, bufx, lane);
+  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(y, T.fA, 0u);
+  transpose_out<LOGN, 0>(y, bufy, lane);
+  wave_lds_sync();
+  transpose_in<LOGN, 0>(x, bufx, lane);
+  transpose_in<LOGN, 0>(y, bufy, lane);
+  wave_lds_sync();
+  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB);
+  transpose_out<LOGN, 1>(x, bufx, lane);
+  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(y, T.fB, lane >> G::PB);
+  transpose_out<LOGN, 1>(y, bufy, lane);
+  wave_lds_sync();
+  transpose_in<LOGN, 1>(x, bufx, lane);
+  transpose_in<LOGN, 1>(y, bufy, lane);
+  wave_lds_sync();
+  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane);
+  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(y, T.fC, lane);
 }
 
 // x: in [0, q], phase-C layout (bit-reversed order) -> coefficients in phase-A layout, each in
@@ -325,6 +364,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   constexpr int N = G::N, R = G::R;
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
   __shared__ uint16_t s_c[VERIFY_WAVES][N];
 
@@ -332,6 +372,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t* buf = s_buf[wave];
+  uint32_t* buf2 = s_buf2[wave];
   uint32_t* pkb = s_pk[wave];
   uint16_t* cbuf = s_c[wave];
   const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
@@ -425,8 +466,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
         y[m] = (int32_t)v;  // <= 16383, reduced by the transform itself
       }
 
-      ntt_forward<LOGN>(x, T, buf, lane);
-      ntt_forward<LOGN>(y, T, buf, lane);
+      ntt_forward2<LOGN>(x, y, T, buf, buf2, lane);
 #pragma unroll
       for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));  // polynomial.hpp:99-110
       ntt_inverse<LOGN>(x, T, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
@@ -485,6 +525,7 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
   constexpr int N = G::N, R = G::R;
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
   fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t* buf = s_buf[wave];
@@ -515,8 +556,7 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
       x[m] = (int32_t)av[m];  // inputs may be any u16 (the reference's ff_t ctor reduces, ff.hpp:69-76): lazy residues
       y[m] = (int32_t)bv[m];
     }
-    ntt_forward<LOGN>(x, T, buf, lane);
-    ntt_forward<LOGN>(y, T, buf, lane);
+    ntt_forward2<LOGN>(x, y, T, buf, s_buf2[wave], lane);
 #pragma unroll
     for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));
     ntt_inverse<LOGN>(x, T, buf, lane, nc);
