@@ -17,7 +17,8 @@ OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVE
 # every symbol include/falcon_amd.h declares
 EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile", "fa_strerror", "fa_verify_many",
            "fa_verify_many_dev", "fa_verify_mixed", "fa_polymul_many", "fa_polymul_many_dev", "fa_pkey_len",
-           "fa_sig_len"]
+           "fa_sig_len", "fa_prepared_key_len", "fa_prepare_keys", "fa_prepare_keys_dev", "fa_verify_many_prepared",
+           "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev"]
 
 
 class FaDebug(ctypes.Structure):
@@ -61,6 +62,14 @@ def load_library():
     lib.fa_verify_mixed.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.fa_polymul_many.argtypes = [vp, i32, sz, vp, vp, vp]
     lib.fa_polymul_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_prepared_key_len.argtypes = [i32]
+    lib.fa_prepared_key_len.restype = sz
+    lib.fa_prepare_keys.argtypes = [vp, i32, sz, vp, vp, vp]
+    lib.fa_prepare_keys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_verify_many_prepared.argtypes = [vp, i32, sz, vp, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug)]
+    lib.fa_verify_many_prepared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug), vp]
+    lib.fa_hash_to_point_many.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp]
+    lib.fa_hash_to_point_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, vp]
     lib.fa_pkey_len.argtypes = [i32]
     lib.fa_pkey_len.restype = sz
     lib.fa_sig_len.argtypes = [i32]
@@ -142,6 +151,73 @@ class Context:
         _check(rc, "fa_verify_many")
         return (accept, out) if debug else accept
 
+    def _msg_args(self, msg, msg_off, count):
+        msg = np.ascontiguousarray(msg, np.uint8)
+        if msg_off is None:
+            if msg.ndim != 2 or msg.shape[0] != count:
+                raise ValueError("msg must be (count, mlen) when msg_off is None")
+            mlen, off = msg.shape[1], None
+        else:
+            off = np.ascontiguousarray(msg_off, np.uint64)
+            if off.shape != (count + 1,):
+                raise ValueError("msg_off must hold count+1 offsets")
+            mlen = 0
+        mp = _ptr(msg) if msg.size else (None if off is None and mlen == 0 else _ptr(np.zeros(8, np.uint8)))
+        return msg, off, mlen, mp
+
+    def prepare_keys(self, logn, pk=None, h=None):
+        """Prepared keys (NTT(h), opaque order) from encoded keys `pk` (nkeys, pklen) or decoded
+        polynomials `h` (nkeys, N) uint16 -- verification::verify's decoded-key form."""
+        if (pk is None) == (h is None):
+            raise ValueError("give exactly one of pk, h")
+        src = np.ascontiguousarray(pk, np.uint8) if pk is not None else np.ascontiguousarray(h, np.uint16)
+        nkeys = src.shape[0]
+        want = self.lib.fa_pkey_len(logn) if pk is not None else (1 << logn)
+        if src.shape != (nkeys, want):
+            raise ValueError("key array shape does not match logn")
+        out = np.zeros((nkeys, 1 << logn), np.uint16)
+        rc = self.lib.fa_prepare_keys(self.handle, logn, nkeys, _ptr(src) if pk is not None else None,
+                                      _ptr(src) if pk is None else None, _ptr(out))
+        _check(rc, "fa_prepare_keys")
+        return out
+
+    def verify_many_prepared(self, logn, prepared, msg, sig, key_idx=None, msg_off=None, norm_policy=NORM_EXACT64,
+                             debug=False):
+        n = 1 << logn
+        prepared = np.ascontiguousarray(prepared, np.uint16)
+        sig = np.ascontiguousarray(sig, np.uint8)
+        count = sig.shape[0]
+        if prepared.ndim != 2 or prepared.shape[1] != n or sig.shape != (count, self.lib.fa_sig_len(logn)):
+            raise ValueError("prepared/sig shape does not match logn")
+        kidx = None if key_idx is None else np.ascontiguousarray(key_idx, np.uint32)
+        if kidx is not None and kidx.shape != (count,):
+            raise ValueError("key_idx must hold count entries")
+        msg, off, mlen, mp = self._msg_args(msg, msg_off, count)
+        accept = np.zeros(count, np.uint8)
+        dbg = out = None
+        if debug:
+            out = {"c": np.zeros((count, n), np.uint16), "s2": np.zeros((count, n), np.int16),
+                   "s1": np.zeros((count, n), np.int16), "norm_exact": np.zeros(count, np.uint64),
+                   "norm_wrap32": np.zeros(count, np.uint32), "status": np.zeros(count, np.uint8)}
+            dbg = FaDebug(*[_ptr(out[k]) for k, _ in FaDebug._fields_])
+        rc = self.lib.fa_verify_many_prepared(self.handle, logn, count, _ptr(prepared), prepared.shape[0], _ptr(kidx), mp,
+                                              _ptr(off), mlen, _ptr(sig), norm_policy, _ptr(accept),
+                                              ctypes.byref(dbg) if dbg is not None else None)
+        _check(rc, "fa_verify_many_prepared")
+        return (accept, out) if debug else accept
+
+    def hash_to_point_many(self, logn, salt, msg, msg_off=None):
+        """hashing::hash_to_point for (count, 40) salts and messages -> (count, N) uint16."""
+        salt = np.ascontiguousarray(salt, np.uint8)
+        count = salt.shape[0]
+        if salt.shape != (count, 40):
+            raise ValueError("salt must be (count, 40)")
+        msg, off, mlen, mp = self._msg_args(msg, msg_off, count)
+        c = np.zeros((count, 1 << logn), np.uint16)
+        _check(self.lib.fa_hash_to_point_many(self.handle, logn, count, _ptr(salt), mp, _ptr(off), mlen, _ptr(c)),
+               "fa_hash_to_point_many")
+        return c
+
     def verify_mixed(self, logn, pk, pk_off, msg, msg_off, sig, sig_off, norm_policy=NORM_EXACT64):
         logn = np.ascontiguousarray(logn, np.uint8)
         count = logn.shape[0]
@@ -176,6 +252,16 @@ class Context:
                                          norm_policy, accept_ptr, ctypes.byref(dbg) if dbg is not None else None,
                                          stream or None)
         _check(rc, "fa_verify_many_dev")
+
+    def prepare_keys_dev(self, logn, nkeys, pk_ptr, h_ptr, prepared_ptr, stream=0):
+        _check(self.lib.fa_prepare_keys_dev(self.handle, logn, nkeys, pk_ptr, h_ptr, prepared_ptr, stream or None),
+               "fa_prepare_keys_dev")
+
+    def verify_many_prepared_dev(self, logn, count, prepared_ptr, key_idx_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr,
+                                 accept_ptr, norm_policy=NORM_EXACT64, stream=0):
+        rc = self.lib.fa_verify_many_prepared_dev(self.handle, logn, count, prepared_ptr, key_idx_ptr, msg_ptr, msg_off_ptr,
+                                                  mlen, sig_ptr, norm_policy, accept_ptr, None, stream or None)
+        _check(rc, "fa_verify_many_prepared_dev")
 
     def polymul_many_dev(self, logn, count, a_ptr, b_ptr, c_ptr, stream=0):
         _check(self.lib.fa_polymul_many_dev(self.handle, logn, count, a_ptr, b_ptr, c_ptr, stream or None),

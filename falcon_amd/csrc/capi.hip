@@ -110,6 +110,12 @@ struct DevBuf {
   }
 };
 
+struct KeySrc {  // where a pass takes its public keys from
+  const uint8_t* pk = nullptr;         // packed keys, one per item
+  const uint16_t* prepared = nullptr;  // or prepared keys (prepare_keys_kernel) ...
+  const uint32_t* key_idx = nullptr;   // ... indexed per item (nullable: key = item)
+};
+
 struct EventPair {
   hipEvent_t a, b;
   int kind;  // 0 decode, 1 hash, 2 verify, 3 polymul
@@ -135,7 +141,7 @@ struct fa_ctx {
   // pipeline workspace (per chunk)
   DevBuf hraw, s2, sqn, st2, retry_count, retry_list, slow_count, slow_list;
   // staging for the host-buffer entry points
-  DevBuf h_pk, h_sig, h_msg, h_off, h_accept, h_dbg[6], h_a, h_b, h_c;
+  DevBuf h_pk, h_sig, h_msg, h_off, h_kidx, h_accept, h_dbg[6], h_a, h_b, h_c;
   std::vector<EventPair> events;
   uint32_t retried = 0;
 };
@@ -179,7 +185,7 @@ bool aligned4(const void* p) { return ((uintptr_t)p & 3u) == 0; }
 // One pass of the three kernels over `slots` items. idx == nullptr: slot s is item s of the arrays
 // given (already offset to the chunk); else item idx[s] of the whole arrays.
 template <int LOGN>
-int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, const uint8_t* pk, const uint8_t* msg,
+int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, const KeySrc& keys, const uint8_t* msg,
              const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, uint32_t nblk, int policy, uint8_t* accept,
              const DebugOut& dbg, bool debug, uint32_t item_base)
 {
@@ -233,7 +239,9 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   if (!idx && ctx->overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
 
   VerifyArgs<LOGN> A;
-  A.pk = pk;
+  A.pk = keys.pk;
+  A.prepared = keys.prepared;
+  A.key_idx = keys.key_idx;
   A.hraw = d_hraw;
   A.s2 = d_s2;
   A.sqn = d_sqn;
@@ -255,16 +263,23 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   const uint32_t want = (slots + VERIFY_WAVES - 1) / VERIFY_WAVES;
   const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * 8u);
   rc = timed(ctx, s, 2, [&] {
-    if (debug)
-      hipLaunchKernelGGL((verify_kernel<LOGN, true>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
-    else
-      hipLaunchKernelGGL((verify_kernel<LOGN, false>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+    if (keys.prepared) {
+      if (debug)
+        hipLaunchKernelGGL((verify_kernel<LOGN, true, true>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+      else
+        hipLaunchKernelGGL((verify_kernel<LOGN, false, true>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+    } else {
+      if (debug)
+        hipLaunchKernelGGL((verify_kernel<LOGN, true, false>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+      else
+        hipLaunchKernelGGL((verify_kernel<LOGN, false, false>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
+    }
   });
   return rc;
 }
 
 template <int LOGN>
-int verify_dev(fa_ctx* ctx, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+int verify_dev(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
                const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
 {
   using G = Geo<LOGN>;
@@ -290,7 +305,10 @@ int verify_dev(fa_ctx* ctx, size_t count, const uint8_t* pk, const uint8_t* msg,
     if (d.norm_exact) d.norm_exact += c0;
     if (d.norm_wrap32) d.norm_wrap32 += c0;
     if (d.status) d.status += c0;
-    rc = run_pass<LOGN>(ctx, s, slots, nullptr, pk + c0 * G::PKLEN, msg_off ? msg : msg + c0 * mlen,
+    KeySrc k = keys;  // this chunk's window of the per-item arrays
+    if (k.pk) k.pk += c0 * G::PKLEN;
+    if (k.key_idx) k.key_idx += c0;
+    rc = run_pass<LOGN>(ctx, s, slots, nullptr, k, msg_off ? msg : msg + c0 * mlen,
                         msg_off ? msg_off + c0 : nullptr, mlen, sig + c0 * SIGLEN, ctx->hash_blocks[T], policy,
                         accept + c0, d, debug, (uint32_t)c0);
     if (rc) return rc;
@@ -312,9 +330,62 @@ int verify_dev(fa_ctx* ctx, size_t count, const uint8_t* pk, const uint8_t* msg,
     if (!rc) rc = (int)hipMemsetAsync(ctx->retry_count.p, 0, 4, s);
     for (uint32_t r0 = 0; !rc && r0 < pending; r0 += ctx->chunk) {
       const uint32_t slots = std::min<uint32_t>(ctx->chunk, pending - r0);
-      rc = run_pass<LOGN>(ctx, s, slots, (const uint32_t*)list.p + r0, pk, msg, msg_off, mlen, sig, nblk, policy, accept,
+      rc = run_pass<LOGN>(ctx, s, slots, (const uint32_t*)list.p + r0, keys, msg, msg_off, mlen, sig, nblk, policy, accept,
                           dbg, debug, 0u);
     }
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    list.release();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// hash_to_point for `count` (salt, message) pairs: SHAKE256 blocks, then rejection sampling; items that need
+// more blocks than squeezed up front are redone with twice as many (same scheme as verify_dev).
+template <int LOGN>
+int hash_to_point_dev(fa_ctx* ctx, size_t count, const uint8_t* salt, const uint8_t* msg, const uint64_t* msg_off,
+                      uint32_t mlen, uint16_t* c, hipStream_t s)
+{
+  constexpr int T = LOGN - 9;
+  int rc;
+  if ((rc = ctx->retry_count.reserve(4))) return rc;
+  if ((rc = ctx->retry_list.reserve(count * 4))) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->retry_count.p, 0, 4, s));
+  const uint8_t* rows = salt - 1;  // hash_kernel reads the salt at bytes 1..40 of a row: rows of 40 bytes starting one byte early
+  auto pass = [&](uint32_t slots, const uint32_t* idx, const uint8_t* rows_, const uint8_t* msg_, const uint64_t* off_,
+                  uint32_t nblk, uint16_t* c_, uint32_t item_base) -> int {
+    int r = ctx->hraw.reserve((size_t)slots * nblk * 136);
+    if (r) return r;
+    r = timed(ctx, s, 1, [&] {
+      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, rows_, 40u, msg_, off_, mlen,
+                         idx, slots, nblk, (uint64_t*)ctx->hraw.p);
+    });
+    if (r) return r;
+    const uint32_t grid = std::min<uint32_t>((slots + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+    hipLaunchKernelGGL(sample_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, (const uint64_t*)ctx->hraw.p, idx, slots, nblk,
+                       item_base, c_, (uint32_t*)ctx->retry_count.p, (uint32_t*)ctx->retry_list.p);
+    return (int)hipGetLastError();
+  };
+  for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
+    const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
+    rc = pass(slots, nullptr, rows + c0 * 40, msg_off ? msg : msg + c0 * mlen, msg_off ? msg_off + c0 : nullptr,
+              ctx->hash_blocks[T], c + (c0 << LOGN), (uint32_t)c0);
+    if (rc) return rc;
+  }
+  uint32_t nblk = ctx->hash_blocks[T];
+  for (;;) {
+    uint32_t pending = 0;
+    HIP_TRY(hipMemcpyAsync(&pending, ctx->retry_count.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (pending == 0) break;
+    ctx->retried += pending;
+    nblk *= 2;
+    DevBuf list;
+    if ((rc = list.reserve((size_t)pending * 4))) return rc;
+    rc = (int)hipMemcpyAsync(list.p, ctx->retry_list.p, (size_t)pending * 4, hipMemcpyDeviceToDevice, s);
+    if (!rc) rc = (int)hipMemsetAsync(ctx->retry_count.p, 0, 4, s);
+    for (uint32_t r0 = 0; !rc && r0 < pending; r0 += ctx->chunk)
+      rc = pass(std::min<uint32_t>(ctx->chunk, pending - r0), (const uint32_t*)list.p + r0, rows, msg, msg_off, nblk, c, 0u);
     if (!rc) rc = (int)hipStreamSynchronize(s);
     list.release();
     if (rc) return rc;
@@ -419,7 +490,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
   }
   DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->slow_count, &ctx->slow_list, &ctx->h_pk,
-                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_accept, &ctx->h_a, &ctx->h_b, &ctx->h_c };
+                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_kidx, &ctx->h_accept, &ctx->h_a, &ctx->h_b, &ctx->h_c };
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : ctx->h_dbg) b.release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -488,18 +559,100 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  return logn == 9 ? verify_dev<9>(ctx, count, pk, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
-                   : verify_dev<10>(ctx, count, pk, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
+  KeySrc keys;
+  keys.pk = pk;
+  return logn == 9 ? verify_dev<9>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
+                   : verify_dev<10>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
 }
 
-int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off,
-                   uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
+int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, const uint32_t* key_idx,
+                                const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig,
+                                int norm_policy, uint8_t* accept, const fa_debug* dbg, void* stream)
 {
   if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
   if (logn != 9 && logn != 10) return FA_E_LOGN;
   if (count == 0) return 0;
-  if (!pk || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  if (!prepared || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
   if (count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (!aligned4(prepared) || !aligned4(key_idx) || !aligned4(sig) || !aligned4(msg) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  KeySrc keys;
+  keys.prepared = prepared;
+  keys.key_idx = key_idx;
+  return logn == 9 ? verify_dev<9>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
+                   : verify_dev<10>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
+}
+
+size_t fa_prepared_key_len(int logn) { return logn == 9 || logn == 10 ? (size_t)2 << logn : 0; }
+
+int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, uint16_t* prepared,
+                        void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (nkeys == 0) return 0;
+  if (!prepared || (!pk) == (!h) || nkeys > 0xFFFFFFFFull) return FA_E_ARG;  // exactly one of pk, h
+  if (!aligned4(prepared) || ((uintptr_t)h & 1u)) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  const int T = logn - 9;
+  const uint32_t n = (uint32_t)nkeys;
+  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+#define FA_LAUNCH_PREP(LN, PACKED)                                                                                      \
+  hipLaunchKernelGGL((prepare_keys_kernel<LN, PACKED>), dim3(grid), dim3(VERIFY_WG), 0, s, pk, h, n, prepared,           \
+                     ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
+  if (logn == 9) {
+    if (pk) FA_LAUNCH_PREP(9, true); else FA_LAUNCH_PREP(9, false);
+  } else {
+    if (pk) FA_LAUNCH_PREP(10, true); else FA_LAUNCH_PREP(10, false);
+  }
+#undef FA_LAUNCH_PREP
+  return (int)hipGetLastError();
+}
+
+int fa_prepare_keys(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, uint16_t* prepared)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (nkeys == 0) return 0;
+  if (!prepared || (!pk) == (!h)) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t in_bytes = nkeys * (pk ? fa_pkey_len(logn) : fa_prepared_key_len(logn));
+  const size_t out_bytes = nkeys * fa_prepared_key_len(logn);
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = ctx->h_pk.reserve(in_bytes + 8))) return rc;
+  if ((rc = ctx->h_c.reserve(out_bytes))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, pk ? (const void*)pk : (const void*)h, in_bytes, hipMemcpyHostToDevice, s));
+  rc = fa_prepare_keys_dev(ctx, logn, nkeys, pk ? (const uint8_t*)ctx->h_pk.p : nullptr, pk ? nullptr : (const uint16_t*)ctx->h_pk.p,
+                           (uint16_t*)ctx->h_c.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(prepared, ctx->h_c.p, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+// Host-buffer front end shared by fa_verify_many and fa_verify_many_prepared: stage the inputs, run the
+// device entry point on the context's private stream, copy the outputs back.
+static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint16_t* prepared, size_t nkeys,
+                       const uint32_t* key_idx, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+                       const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
+{
+  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if ((!pk && !prepared) || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  if (count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (prepared) {  // every item must name an existing key
+    if (nkeys == 0 || nkeys > 0xFFFFFFFFull || (!key_idx && nkeys < count)) return FA_E_ARG;
+    if (key_idx)
+      for (size_t i = 0; i < count; i++)
+        if (key_idx[i] >= nkeys) return FA_E_ARG;
+  }
   Guard g(ctx->device);
   if (g.err) return g.err;
   const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);
@@ -509,14 +662,15 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
   const size_t first = msg_off ? (size_t)msg_off[0] : 0;
   if (msg_off && (size_t)msg_off[count] < first) return FA_E_ARG;
   const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;
+  const size_t key_bytes = prepared ? nkeys * n * 2 : count * pklen;
   hipStream_t s = ctx->stream;
   int rc;
   // +8 bytes of slack: the kernels read whole aligned dwords around the last record
-  if ((rc = ctx->h_pk.reserve(count * pklen + 8))) return rc;
+  if ((rc = ctx->h_pk.reserve(key_bytes + 8))) return rc;
   if ((rc = ctx->h_sig.reserve(count * siglen + 8))) return rc;
   if ((rc = ctx->h_msg.reserve(msg_bytes + 12))) return rc;
   if ((rc = ctx->h_accept.reserve(count))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, pk, count * pklen, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, prepared ? (const void*)prepared : (const void*)pk, key_bytes, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->h_sig.p, sig, count * siglen, hipMemcpyHostToDevice, s));
   uint8_t* d_msg_stage = (uint8_t*)ctx->h_msg.p + (first & 3u);
   if (msg_bytes) HIP_TRY(hipMemcpyAsync(d_msg_stage, msg + first, msg_bytes, hipMemcpyHostToDevice, s));
@@ -527,9 +681,15 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
     HIP_TRY(hipMemcpyAsync(ctx->h_off.p, msg_off, (count + 1) * 8, hipMemcpyHostToDevice, s));
     d_off = (const uint64_t*)ctx->h_off.p;
   }
+  const uint32_t* d_kidx = nullptr;
+  if (prepared && key_idx) {
+    if ((rc = ctx->h_kidx.reserve(count * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_kidx.p, key_idx, count * 4, hipMemcpyHostToDevice, s));
+    d_kidx = (const uint32_t*)ctx->h_kidx.p;
+  }
   fa_debug d{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  const size_t sz[6] = { count * n * 2, count * n * 2, count * n * 2, count * 8, count * 4, count };
   if (dbg) {
-    const size_t sz[6] = { count * n * 2, count * n * 2, count * n * 2, count * 8, count * 4, count };
     void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
     void** dev[6] = { (void**)&d.c, (void**)&d.s2, (void**)&d.s1, (void**)&d.norm_exact, (void**)&d.norm_wrap32,
                       (void**)&d.status };
@@ -539,18 +699,36 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
       *dev[i] = ctx->h_dbg[i].p;
     }
   }
-  rc = fa_verify_many_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, d_msg, d_off, mlen,
-                          (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
+  if (prepared)
+    rc = fa_verify_many_prepared_dev(ctx, logn, count, (const uint16_t*)ctx->h_pk.p, d_kidx, d_msg, d_off, mlen,
+                                     (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
+  else
+    rc = fa_verify_many_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, d_msg, d_off, mlen,
+                            (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(accept, ctx->h_accept.p, count, hipMemcpyDeviceToHost, s));
   if (dbg) {
-    const size_t sz[6] = { count * n * 2, count * n * 2, count * n * 2, count * 8, count * 4, count };
     void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
     for (int i = 0; i < 6; i++)
       if (host[i]) HIP_TRY(hipMemcpyAsync(host[i], ctx->h_dbg[i].p, sz[i], hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
+}
+
+int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off,
+                   uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
+{
+  if (!pk && count) return FA_E_ARG;
+  return verify_host(ctx, logn, count, pk, nullptr, 0, nullptr, msg, msg_off, mlen, sig, norm_policy, accept, dbg);
+}
+
+int fa_verify_many_prepared(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, size_t nkeys,
+                            const uint32_t* key_idx, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+                            const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
+{
+  if (!prepared && count) return FA_E_ARG;
+  return verify_host(ctx, logn, count, nullptr, prepared, nkeys, key_idx, msg, msg_off, mlen, sig, norm_policy, accept, dbg);
 }
 
 int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
@@ -584,6 +762,55 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
     if (rc) return rc;
     for (size_t k = 0; k < who.size(); k++) accept[who[k]] = gacc[k];
   }
+  return 0;
+}
+
+int fa_hash_to_point_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* salt, const uint8_t* msg,
+                              const uint64_t* msg_off, uint32_t mlen, uint16_t* c, void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!salt || !c || (!msg && (msg_off || mlen)) || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (!aligned4(salt) || !aligned4(msg) || !aligned4(c) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  return logn == 9 ? hash_to_point_dev<9>(ctx, count, salt, msg, msg_off, mlen, c, (hipStream_t)stream)
+                   : hash_to_point_dev<10>(ctx, count, salt, msg, msg_off, mlen, c, (hipStream_t)stream);
+}
+
+int fa_hash_to_point_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* salt, const uint8_t* msg,
+                          const uint64_t* msg_off, uint32_t mlen, uint16_t* c)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!salt || !c || (!msg && (msg_off || mlen)) || count > 0xFFFFFFFFull) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t first = msg_off ? (size_t)msg_off[0] : 0;
+  if (msg_off && (size_t)msg_off[count] < first) return FA_E_ARG;
+  const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;
+  const size_t out_bytes = (count << logn) * 2;
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = ctx->h_sig.reserve(count * 40 + 16))) return rc;
+  if ((rc = ctx->h_msg.reserve(msg_bytes + 12))) return rc;
+  if ((rc = ctx->h_c.reserve(out_bytes))) return rc;
+  uint8_t* d_salt = (uint8_t*)ctx->h_sig.p + 4;  // the kernel's row pointer is salt - 1
+  HIP_TRY(hipMemcpyAsync(d_salt, salt, count * 40, hipMemcpyHostToDevice, s));
+  uint8_t* d_msg_stage = (uint8_t*)ctx->h_msg.p + (first & 3u);
+  if (msg_bytes) HIP_TRY(hipMemcpyAsync(d_msg_stage, msg + first, msg_bytes, hipMemcpyHostToDevice, s));
+  const uint64_t* d_off = nullptr;
+  if (msg_off) {
+    if ((rc = ctx->h_off.reserve((count + 1) * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_off.p, msg_off, (count + 1) * 8, hipMemcpyHostToDevice, s));
+    d_off = (const uint64_t*)ctx->h_off.p;
+  }
+  rc = fa_hash_to_point_many_dev(ctx, logn, count, d_salt, d_msg_stage - first, d_off, mlen, (uint16_t*)ctx->h_c.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c, ctx->h_c.p, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
 

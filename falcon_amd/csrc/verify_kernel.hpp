@@ -296,7 +296,9 @@ struct DebugOut {  // device pointers, any may be null
 
 template <int LOGN>
 struct VerifyArgs {
-  const uint8_t* pk;        // [items][PKLEN]
+  const uint8_t* pk;        // [items][PKLEN]                       (packed-key kernels)
+  const uint16_t* prepared; // [keys][N] prepared keys, see prepare_keys_kernel (prepared-key kernels)
+  const uint32_t* key_idx;  // item -> key, nullable (then key = item_base + item)
   const uint64_t* hraw;     // [slots][nblk*17]
   const uint16_t* s2;       // lifted s2 in the tiled layout of s2_tile_offset (decode kernels)
   const uint32_t* sqn;      // [slots]
@@ -317,17 +319,90 @@ struct VerifyArgs {
   DebugOut dbg;
 };
 
+constexpr uint32_t PREPARED_BAD_KEY = 0xffffu;  // first coefficient of a prepared key whose header was wrong
+
+// decode_pkey body (decoding.hpp:34-45): the key row, held as aligned dwords t*64+lane with the header
+// at byte `pal` of dword 0, goes through LDS so that each lane can pick its 14-bit little-endian fields
+// (phase-A layout, raw values <= 16383).
+template <int LOGN>
+__device__ __forceinline__ void unpack_pkey(const uint32_t (&pkw)[Geo<LOGN>::PKDW], uint32_t pal, uint32_t* __restrict__ pkb,
+                                            uint32_t lane, int32_t (&y)[Geo<LOGN>::R])
+{
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int t = 0; t < G::PKDW; t++) pkb[t * 64 + lane] = pkw[t];
+  wave_lds_sync();
+#pragma unroll
+  for (int m = 0; m < G::R; m++) {
+    const uint32_t bit = (pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
+    const uint32_t dw = bit >> 5, sh = bit & 31u;
+    const uint32_t lo = pkb[dw], hi = pkb[min(dw + 1u, (uint32_t)G::PKDW * 64u - 1u)];
+    y[m] = (int32_t)(__builtin_amdgcn_alignbit(hi, lo, sh) & 0x3fffu);  // <= 16383, reduced by the transform itself
+  }
+}
+
+// Prepared keys: NTT(h) of a public key, canonical u16, in the order the verify kernel consumes it
+// (lane L holds positions L*R .. L*R+R-1 of the transform's bit-reversed output). One wave per key.
+// PACKED: input rows are encoded keys (decode_pkey, decoding.hpp:18-48; a wrong header yields the
+// PREPARED_BAD_KEY mark, the counterpart of falcon.hpp:240-243); else rows are decoded polynomials h as
+// verification::verify takes them (N u16, any value: the ff_t arithmetic reduces, ff.hpp:69-76).
+template <int LOGN, bool PACKED>
+__global__ __launch_bounds__(VERIFY_WG) void prepare_keys_kernel(const uint8_t* __restrict__ pk, const uint16_t* __restrict__ h,
+                                                                 uint32_t nkeys, uint16_t* __restrict__ prepared,
+                                                                 const Tw* __restrict__ tw, const Tw* __restrict__ itw,
+                                                                 const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                                 const NttConsts nc)
+{
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, R = G::R;
+  __shared__ TwLds<LOGN> s_tw;
+  __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
+  for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < nkeys; key += gridDim.x * VERIFY_WAVES) {
+    int32_t y[R];
+    bool ok = true;
+    if constexpr (PACKED) {
+      const uint8_t* pkrow = pk + (size_t)key * G::PKLEN;
+      const uint32_t pal = (uint32_t)((uintptr_t)pkrow & 3u);
+      const uint32_t* pbase = (const uint32_t*)(pkrow - pal);
+      const uint32_t last_dw = (pal + (uint32_t)G::PKLEN - 1u) >> 2;
+      uint32_t pkw[G::PKDW];
+#pragma unroll
+      for (int t = 0; t < G::PKDW; t++) pkw[t] = pbase[min(t * 64u + lane, last_dw)];
+      ok = ((__builtin_amdgcn_readfirstlane(pkw[0]) >> (8u * __builtin_amdgcn_readfirstlane(pal))) & 0xffu) == (uint32_t)LOGN;
+      unpack_pkey<LOGN>(pkw, pal, s_pk[wave], lane, y);
+    } else {
+#pragma unroll
+      for (int m = 0; m < R; m++) y[m] = (int32_t)h[(size_t)key * N + idxA<LOGN>(lane, m)];
+    }
+    ntt_forward<LOGN>(y, T, s_buf[wave], lane);
+    uint32_t* out = (uint32_t*)(prepared + (size_t)key * N) + lane * (R / 2);
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) {
+      uint32_t lo = csub((uint32_t)reduce(y[2 * j]), Q), hi = csub((uint32_t)reduce(y[2 * j + 1]), Q);
+      if (!ok) lo = hi = 0u;
+      if (!ok && j == 0 && lane == 0) lo = PREPARED_BAD_KEY;
+      out[j] = lo | (hi << 16);
+    }
+    wave_lds_sync();
+  }
+}
+
 // Everything one item needs from HBM, loaded one item ahead of its use so that the latency of
 // the loads hides behind the previous item's transforms.
 template <int LOGN>
 struct ItemRegs {
   uint32_t hw[Geo<LOGN>::MAXHW];   // squeezed blocks, dword t*64+lane
   uint32_t s2v[Geo<LOGN>::R];      // s2[m*64 + lane]
-  uint32_t pkw[Geo<LOGN>::PKDW];   // key row, aligned dword t*64+lane
+  uint32_t pkw[Geo<LOGN>::PKDW];   // key row, aligned dword t*64+lane          (packed keys)
+  uint32_t hk[Geo<LOGN>::R / 2];   // prepared key, coefficients lane*R .. lane*R+R-1, two per dword
   uint32_t sqn, st, item, pal;
 };
 
-template <int LOGN>
+template <int LOGN, bool PREPARED>
 __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_t slot, uint32_t lane, ItemRegs<LOGN>& r)
 {
   using G = Geo<LOGN>;
@@ -344,20 +419,32 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   const uint16_t* s2row = A.s2 + s2_tile_offset<LOGN>(slot, 0u);  // tiled: chunk stride 64*32, see decode_kernel.hpp
 #pragma unroll
   for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];  // i = 64 m + lane
-  const uint8_t* pkrow = A.pk + (size_t)r.item * G::PKLEN;
-  r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
-  const uint32_t* pbase = (const uint32_t*)(pkrow - r.pal);
-  const uint32_t last_dw = (r.pal + (uint32_t)G::PKLEN - 1u) >> 2;
+  if constexpr (PREPARED) {
+    uint32_t key = A.key_idx ? A.key_idx[r.item] : A.item_base + r.item;
+    key = __builtin_amdgcn_readfirstlane(key);
+    const uint32_t* krow = (const uint32_t*)(A.prepared + (size_t)key * G::N);
 #pragma unroll
-  for (int t = 0; t < G::PKDW; t++) {
-    const uint32_t d = t * 64u + lane;
-    r.pkw[t] = pbase[min(d, last_dw)];
+    for (int j = 0; j < G::R / 2; j++) r.hk[j] = krow[lane * (G::R / 2) + j];
+    r.pal = 0u;
+  } else {
+    const uint8_t* pkrow = A.pk + (size_t)r.item * G::PKLEN;
+    r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
+    const uint32_t* pbase = (const uint32_t*)(pkrow - r.pal);
+    const uint32_t last_dw = (r.pal + (uint32_t)G::PKLEN - 1u) >> 2;
+#pragma unroll
+    for (int t = 0; t < G::PKDW; t++) {
+      const uint32_t d = t * 64u + lane;
+      r.pkw[t] = pbase[min(d, last_dw)];
+    }
   }
   r.sqn = A.sqn[slot];
   r.st = A.st2[slot];
 }
 
-template <int LOGN, bool DEBUG>
+// PREPARED: the public key arrives as NTT(h) (prepare_keys_kernel) instead of packed bytes -- the
+// decoded-key form of verification::verify<N, beta2>(h, ...) (verification.hpp:20-26, falcon.hpp:226-229) for
+// callers that verify many signatures per key: no unpacking and one forward transform less per item.
+template <int LOGN, bool DEBUG, bool PREPARED>
 __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN> A)
 {
   using G = Geo<LOGN>;
@@ -381,19 +468,23 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   uint32_t slot = blockIdx.x * VERIFY_WAVES + wave;
   if (slot >= A.count) return;
   ItemRegs<LOGN> cur;
-  prefetch_item<LOGN>(A, slot, lane, cur);
+  prefetch_item<LOGN, PREPARED>(A, slot, lane, cur);
 
   while (true) {
     const uint32_t nslot = slot + nwaves;
     const bool more = nslot < A.count;  // wave-uniform
     ItemRegs<LOGN> nxt;
-    if (more) prefetch_item<LOGN>(A, nslot, lane, nxt);
+    if (more) prefetch_item<LOGN, PREPARED>(A, nslot, lane, nxt);
 
     const uint32_t item = cur.item;
     // header byte of the key row = byte `pal` of aligned dword 0 (lane 0 holds it); falcon.hpp:240-243
-    const uint32_t hdr = (__builtin_amdgcn_readfirstlane(cur.pkw[0]) >> (8u * __builtin_amdgcn_readfirstlane(cur.pal))) & 0xffu;
     uint32_t status = __builtin_amdgcn_readfirstlane(cur.st);
-    if (hdr != (uint32_t)LOGN) status = ST_BAD_PK_HEADER;  // checked before the signature, as the reference does
+    if constexpr (PREPARED) {  // a key whose header was wrong is marked by 0xffff in its first coefficient
+      if ((__builtin_amdgcn_readfirstlane(cur.hk[0]) & 0xffffu) == PREPARED_BAD_KEY) status = ST_BAD_PK_HEADER;
+    } else {
+      const uint32_t hdr = (__builtin_amdgcn_readfirstlane(cur.pkw[0]) >> (8u * __builtin_amdgcn_readfirstlane(cur.pal))) & 0xffu;
+      if (hdr != (uint32_t)LOGN) status = ST_BAD_PK_HEADER;  // checked before the signature, as the reference does
+    }
 
     bool done = false;
     uint32_t have = 0;  // accepted draws so far (wave-uniform)
@@ -451,24 +542,22 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
 #pragma unroll
       for (int m = 0; m < R; m++) x[m] = (int32_t)cur.s2v[m];
 
-      // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
-      //      lazily (equivalent to the reference's raw values). The row was loaded
-      //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
+      if constexpr (PREPARED) {
+        ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
-      for (int t = 0; t < G::PKDW; t++) pkb[t * 64 + lane] = cur.pkw[t];
-      wave_lds_sync();
+        for (int m = 0; m < R; m++) {  // NTT(h), canonical, already in this lane's phase-C positions
+          const uint32_t hv = (cur.hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
+          x[m] = mulmod(reduce(x[m]), (int32_t)hv);  // polynomial.hpp:99-110
+        }
+      } else {
+        // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
+        //      lazily (equivalent to the reference's raw values). The row was loaded
+        //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
+        unpack_pkey<LOGN>(cur.pkw, cur.pal, pkb, lane, y);
+        ntt_forward2<LOGN>(x, y, T, buf, buf2, lane);
 #pragma unroll
-      for (int m = 0; m < R; m++) {
-        const uint32_t bit = (cur.pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
-        const uint32_t dw = bit >> 5, sh = bit & 31u;
-        const uint32_t lo = pkb[dw], hi = pkb[min(dw + 1u, (uint32_t)G::PKDW * 64u - 1u)];
-        const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, sh) & 0x3fffu;
-        y[m] = (int32_t)v;  // <= 16383, reduced by the transform itself
+        for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));  // polynomial.hpp:99-110
       }
-
-      ntt_forward2<LOGN>(x, y, T, buf, buf2, lane);
-#pragma unroll
-      for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));  // polynomial.hpp:99-110
       ntt_inverse<LOGN>(x, T, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
 
       // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
@@ -509,6 +598,50 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
     if (!more) break;
     cur = nxt;
     slot = nslot;
+  }
+}
+
+// ---- standalone hash_to_point (hashing.hpp:16-50): the rejection-sampling half on its own ----
+// One wave per item: the squeezed SHAKE256 blocks of hash_kernel -> c[item][N] (u16, canonical), in draw
+// order. Items that run out of blocks are queued in retry_list, as in the verify kernel.
+template <int LOGN>
+__global__ __launch_bounds__(VERIFY_WG) void sample_kernel(const uint64_t* __restrict__ hraw, const uint32_t* __restrict__ idx,
+                                                           uint32_t count, uint32_t nblk, uint32_t item_base,
+                                                           uint16_t* __restrict__ c, uint32_t* __restrict__ retry_count,
+                                                           uint32_t* __restrict__ retry_list)
+{
+  constexpr uint32_t N = 1u << LOGN;
+  __shared__ uint16_t s_c[VERIFY_WAVES][N];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint16_t* cbuf = s_c[wave];
+  const uint32_t ndw = nblk * 34u;
+  for (uint32_t slot = blockIdx.x * VERIFY_WAVES + wave; slot < count; slot += gridDim.x * VERIFY_WAVES) {
+    const uint32_t item = idx ? idx[slot] : slot;
+    const uint32_t* hrow = (const uint32_t*)(hraw + (size_t)slot * nblk * 17u);
+    uint32_t have = 0;  // accepted draws so far (wave-uniform)
+    for (uint32_t base = 0; base < ndw && have < N; base += 64u) {
+      const uint32_t d = base + lane;
+      const uint32_t w = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are always rejected
+      const uint32_t t0 = ((w & 0xffu) << 8) | ((w >> 8) & 0xffu);  // big-endian 16-bit draws, hashing.hpp:42-43
+      const uint32_t t1 = ((w >> 8) & 0xff00u) | (w >> 24);
+      const bool a0 = t0 < 61445u, a1 = t1 < 61445u;                // hashing.hpp:25-28,44
+      const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+      const uint32_t p0 = have + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
+                          __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+      const uint32_t p1 = p0 + (a0 ? 1u : 0u);
+      if (a0 && p0 < N) cbuf[p0] = (uint16_t)mod_q_17(t0);          // ff_t{t}, hashing.hpp:45
+      if (a1 && p1 < N) cbuf[p1] = (uint16_t)mod_q_17(t1);
+      have += __popcll(m0) + __popcll(m1);
+    }
+    wave_lds_sync();
+    if (have < N) {
+      if (lane == 0) retry_list[atomicAdd(retry_count, 1u)] = item_base + item;
+    } else {
+      uint32_t* out = (uint32_t*)(c + (size_t)item * N);
+      const uint32_t* src = (const uint32_t*)cbuf;
+      for (uint32_t j = lane; j < N / 2; j += 64u) out[j] = src[j];
+    }
+    wave_lds_sync();
   }
 }
 

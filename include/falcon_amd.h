@@ -91,6 +91,38 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
                        const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
                        uint8_t* accept, const fa_debug* dbg, void* stream);
 
+/* ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
+ * For callers that keep public keys decoded and verify many signatures per key (falcon.hpp:226-229,
+ * benchmarks/bench_signing.cpp:105). A key is prepared once -- decoded and carried into the NTT domain,
+ * N uint16 values in this library's own coefficient order (an opaque blob of fa_prepared_key_len bytes,
+ * valid for any context of the same logn) -- and items then name their key by index. Per item this saves
+ * the key unpacking and one of the two forward transforms, and 897/1793 bytes of input.
+ *
+ * fa_prepare_keys: exactly one of `pk` (nkeys encoded keys, decode_pkey, decoding.hpp:18-48; a key with a
+ * wrong header is marked and every item using it is rejected, as falcon.hpp:240-243 does) and `h` (nkeys
+ * decoded polynomials, N uint16 each, natural order, any values: taken mod q as ff_t does) is non-NULL.
+ * key_idx == NULL: item i uses key i (needs nkeys >= count). The host variant checks key_idx[i] < nkeys;
+ * the device variant cannot and leaves that to the caller. */
+size_t fa_prepared_key_len(int logn);
+int fa_prepare_keys(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, uint16_t* prepared);
+int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, uint16_t* prepared,
+                        void* stream); /* asynchronous on `stream` */
+int fa_verify_many_prepared(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, size_t nkeys,
+                            const uint32_t* key_idx, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+                            const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg);
+int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, const uint32_t* key_idx,
+                                const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig,
+                                int norm_policy, uint8_t* accept, const fa_debug* dbg, void* stream);
+
+/* ---- hashing::hash_to_point<n>(salt, 40, msg, mlen, poly), hashing.hpp:16-50, as a batched primitive ----
+ * (also the first step of signing, signing.hpp:48-49). salt: count*40 bytes; messages as in fa_verify_many;
+ * c: count*N uint16, canonical residues in draw order. _dev: device pointers (4-byte aligned), work is
+ * enqueued on `stream` and the call synchronises it once. */
+int fa_hash_to_point_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* salt, const uint8_t* msg,
+                          const uint64_t* msg_off, uint32_t mlen, uint16_t* c);
+int fa_hash_to_point_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* salt, const uint8_t* msg,
+                              const uint64_t* msg_off, uint32_t mlen, uint16_t* c, void* stream);
+
 /* Mixed Falcon-512 / Falcon-1024 batch, host buffers: logn[i] in {9,10}; item i's key, signature and
  * message are pk[pk_off[i]..], sig[sig_off[i]..], msg[msg_off[i]..msg_off[i+1]). The host splits the
  * batch by N and runs one pass per class. */

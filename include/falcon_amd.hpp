@@ -6,6 +6,9 @@
 //
 //   falcon::verify<N>(pkey, msg, mlen, sig)            falcon.hpp:230-249   same signature, same bool
 //   falcon::verify_many<N>(count, pkeys, msgs, ...)    no counterpart: `count` independent calls of the above
+//   falcon::prepared_keys<N> + verify_many<N>(count, keys, key_idx, ...)
+//                                                      verification.hpp:20-26   verify with the key kept decoded
+//   falcon::hash_to_point_many<N>(count, salts, ...)   hashing.hpp:16-50
 //
 // Both run on the GPU through the C ABI of falcon_amd.h (libfalcon_amd.so); there is no CPU path
 // in this header. Conventions are the reference's: the caller owns every
@@ -146,6 +149,58 @@ inline void verify_many_sharded(size_t count, const uint8_t* pkeys, const uint8_
   for (auto& w : workers) w.join();
   for (auto& e : errors)
     if (e) std::rethrow_exception(e);
+}
+
+// ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
+// Keys are prepared once (decoded + forward NTT, kept in HBM-friendly uint16 form on the host side here)
+// and reused for any number of signatures; beta2 is implied by N (falcon.hpp:245-246).
+template<size_t N>
+class prepared_keys
+{
+public:
+  // from encoded public keys (decode_pkey, decoding.hpp:18-48); a key with a wrong header rejects every item using it
+  static prepared_keys from_encoded(size_t nkeys, const uint8_t* pkeys, int device = 0)
+  {
+    prepared_keys k(nkeys);
+    const int rc = fa_prepare_keys(detail::context(device), detail::logn<N>(), nkeys, pkeys, nullptr, k.blob_.data());
+    if (rc) throw device_error("fa_prepare_keys", rc);
+    return k;
+  }
+  // from decoded polynomials h (N coefficients each, natural order), the type verification::verify takes
+  static prepared_keys from_decoded(size_t nkeys, const uint16_t* h, int device = 0)
+  {
+    prepared_keys k(nkeys);
+    const int rc = fa_prepare_keys(detail::context(device), detail::logn<N>(), nkeys, nullptr, h, k.blob_.data());
+    if (rc) throw device_error("fa_prepare_keys", rc);
+    return k;
+  }
+  size_t size() const { return nkeys_; }
+  const uint16_t* data() const { return blob_.data(); }
+
+private:
+  explicit prepared_keys(size_t nkeys) : nkeys_(nkeys), blob_(nkeys * N) {}
+  size_t nkeys_;
+  std::vector<uint16_t> blob_;
+};
+
+// Item i is checked against keys[key_idx[i]] (key_idx == nullptr: against keys[i]).
+template<size_t N>
+inline void verify_many(size_t count, const prepared_keys<N>& keys, const uint32_t* key_idx, const uint8_t* msgs, size_t mlen,
+                        const uint64_t* msg_off, const uint8_t* sigs, uint8_t* accept, int device = 0,
+                        norm_policy policy = norm_policy::exact)
+{
+  const int rc = fa_verify_many_prepared(detail::context(device), detail::logn<N>(), count, keys.data(), keys.size(), key_idx,
+                                         msgs, msg_off, (uint32_t)mlen, sigs, (int)policy, accept, nullptr);
+  if (rc) throw device_error("fa_verify_many_prepared", rc);
+}
+
+// hashing::hash_to_point<N>(salt, 40, msg, mlen, poly) (hashing.hpp:16-50) for `count` (salt, message) pairs.
+template<size_t N>
+inline void hash_to_point_many(size_t count, const uint8_t* salts, const uint8_t* msgs, size_t mlen, const uint64_t* msg_off,
+                               uint16_t* c, int device = 0)
+{
+  const int rc = fa_hash_to_point_many(detail::context(device), detail::logn<N>(), count, salts, msgs, msg_off, (uint32_t)mlen, c);
+  if (rc) throw device_error("fa_hash_to_point_many", rc);
 }
 
 // falcon.hpp:230-249. `sig` is non-const there too (never written).

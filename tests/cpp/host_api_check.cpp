@@ -4,7 +4,8 @@
 //
 // usage: host_api_check <logn> <count> <mlen> <pk.bin> <msg.bin> <sig.bin> <ndev>
 // prints one line of '0'/'1' accept flags from verify_many<N>, a second line from per-item
-// verify<N> calls on the first min(count, 8) items, and a third from verify_many_sharded<N>.
+// verify<N> calls on the first min(count, 8) items, a third from the prepared-key form, and a fourth from
+// verify_many_sharded<N>.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -41,6 +42,13 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     std::putchar(ok ? '1' : '0');
   }
   std::putchar('\n');
+  {  // decoded-key form: keys prepared once, item i against key i
+    auto keys = falcon::prepared_keys<N>::from_encoded(count, pk.data());
+    std::vector<uint8_t> acc3(count, 7);
+    falcon::verify_many<N>(count, keys, nullptr, msg.data(), mlen, nullptr, sig.data(), acc3.data());
+    for (uint8_t a : acc3) std::putchar('0' + a);
+    std::putchar('\n');
+  }
   std::vector<uint8_t> acc2(count, 7);
   falcon::verify_many_sharded<N>(count, pk.data(), msg.data(), mlen, nullptr, sig.data(), acc2.data(), ndev);
   for (uint8_t a : acc2) std::putchar('0' + a);

@@ -20,8 +20,9 @@ def test_cpp_verify_and_verify_many(tmp_path, oracle, corpus, logn):
     out = subprocess.run([EXE, str(logn), str(count), "32", str(tmp_path / "pk.bin"), str(tmp_path / "msg.bin"),
                           str(tmp_path / "sig.bin"), "1"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    many, single, sharded = out.stdout.split("\n")[:3]
+    many, single, prepared, sharded = out.stdout.split("\n")[:4]
     want = "".join(str(int(f) & 1) for f in oracle.verify_many(logn, pk, msg, sig)[0])
     assert many == want
     assert single == want[:8]
+    assert prepared == want
     assert sharded == want

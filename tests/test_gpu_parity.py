@@ -143,3 +143,60 @@ def test_argument_errors(ctx):
     assert lib.fa_verify_many(ctx.handle, 9, 1, p(z), p(z), None, 32, p(z), 7, p(acc), None) == -1   # bad policy
     assert lib.fa_verify_many_dev(ctx.handle, 9, 1, 0x1001, 0x1000, None, 32, 0x1000, 0, 0x1000, None, None) == -3  # FA_E_ALIGN
     assert lib.fa_set_option(ctx.handle, 99, 1) == -1
+
+
+# ---- decoded-key fast path and standalone hash_to_point ----
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_prepared_keys_many_signatures_per_key(ctx, oracle, corpus, logn):
+    """verification::verify<N, beta2>(h, ...) (verification.hpp:20-26): keys prepared once from their encoded
+    form and from the decoded polynomial, items name their key by index; results must equal the packed-key path
+    and the oracle, including a key with a wrong header and keys with coefficients >= q."""
+    n = 1 << logn
+    count, nkeys = 600, 40
+    pk, msg, sig, kinds = corpus.generate(logn, count, seed=31 + logn, malformed_permille=300)
+    flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
+    # one prepared key per item (key_idx = None)
+    prep = ctx.prepare_keys(logn, pk=pk)
+    assert prep.shape == (count, n)
+    acc, gdbg = ctx.verify_many_prepared(logn, prep, msg, sig, debug=True)
+    _compare_debug(logn, flags, odbg, acc, gdbg)
+    accw = ctx.verify_many_prepared(logn, prep, msg, sig, norm_policy=1)
+    np.testing.assert_array_equal(accw, (flags >> 1) & 1)
+    # decoded-polynomial input gives the same prepared blob for keys whose header is right
+    good = pk[:, 0] == logn
+    h = np.stack([oracle.decode_pkey(logn, k)[1] for k in pk[good]])
+    np.testing.assert_array_equal(ctx.prepare_keys(logn, h=h), prep[good])
+    # a few keys shared by many items: every item is checked against key (i % nkeys), so most fail the norm
+    kidx = (np.arange(count) % nkeys).astype(np.uint32)
+    want, wdbg = oracle.verify_many(logn, pk[kidx], msg, sig, debug=True, threads=8)
+    acc2, gdbg2 = ctx.verify_many_prepared(logn, prep[:nkeys], msg, sig, key_idx=kidx, debug=True)
+    _compare_debug(logn, want, wdbg, acc2, gdbg2)
+    assert acc2[:nkeys].tolist() == (flags[:nkeys] & 1).tolist()
+    with pytest.raises(Exception):
+        ctx.verify_many_prepared(logn, prep[:nkeys], msg, sig, key_idx=kidx + 1)  # index out of range is refused
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_hash_to_point_many(oracle, logn):
+    """hashing::hash_to_point (hashing.hpp:16-50) as a batched primitive, messages of 0..1024 bytes; a private
+    context with too few squeeze blocks exercises the re-hash pass."""
+    from falcon_amd import capi
+    rng = np.random.default_rng(logn)
+    lens = [0, 1, 32, 95, 96, 135, 136, 137, 500, 1024] * 13
+    salt = rng.integers(0, 256, (len(lens), 40), dtype=np.uint8)
+    msgs = [rng.integers(0, 256, m, dtype=np.uint8) for m in lens]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    flat = np.concatenate(msgs)
+    want = np.stack([oracle.hash_to_point(logn, salt[i], msgs[i])[0] for i in range(len(lens))])
+    c = capi.Context(0)
+    try:
+        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)
+        c.set_option(capi.OPT_HASH_BLOCKS_512 if logn == 9 else capi.OPT_HASH_BLOCKS_1024, 8 if logn == 9 else 16)
+        c.set_option(capi.OPT_CHUNK_ITEMS, 64)
+        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)
+        assert c.get_profile()["retried_items"] > 0
+        fixed = np.stack([m for m in msgs if m.size == 32])
+        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt[np.array(lens) == 32], fixed), want[np.array(lens) == 32])
+    finally:
+        c.close()
