@@ -55,6 +55,10 @@ def main():
                     help="9 = Falcon-512 (the headline workload, BASELINE.json configs[2]); 10 = Falcon-1024 (A/B runs only)")
     ap.add_argument("--malformed", type=int, default=0, help="permille of malformed items in the timed corpus (A/B runs only)")
     ap.add_argument("--overlap", type=int, default=-1, help="override FA_OPT_OVERLAP (A/B runs only)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process group for the barrier and the max-over-ranks timing; gloo + --same-gpu rehearses the "
+                         "N > 1 path on a one-GPU box")
+    ap.add_argument("--same-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -67,10 +71,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the two scalar reductions live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import falcon_amd
     from falcon_amd import capi
@@ -119,10 +129,10 @@ def main():
     ctx.set_option(capi.OPT_PROFILE, 0)
     accepted = int(d_acc.sum().item())
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        a = torch.tensor([accepted], dtype=torch.int64, device=dev)
+        a = torch.tensor([accepted], dtype=torch.int64, device=red_dev)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         accepted = int(a.item())
 
@@ -215,6 +225,16 @@ def main():
             "accepted_fraction": float(e_acc.float().mean().item()),
             "accept_mismatches_vs_oracle_first_16384": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum())}
         del e_pk, e_msg, e_sig, e_acc
+        # host-buffer entry point (fa_verify_many: H2D staging + kernels + D2H), pageable numpy memory: the
+        # PCIe-inclusive rate that DESIGN.md section 7 quotes; never the headline value
+        nh = min(n_items, 1 << 19)
+        ctx.verify_many(logn, pk[:nh], msg[:nh], sig[:nh])
+        t0 = time.perf_counter()
+        h_acc = ctx.verify_many(logn, pk[:nh], msg[:nh], sig[:nh])
+        dt = time.perf_counter() - t0
+        extras["host_buffers_pcie_inclusive"] = {"verifies_per_s": nh / dt, "items": nh,
+                                                 "input_GBps": nh * (pk.shape[1] + sig.shape[1] + 32) / dt / 1e9,
+                                                 "accepted_fraction": float(h_acc.mean())}
         # decoded-key fast path: keys prepared once (NTT(h) resident), same 2^20 Falcon-512 items
         if logn == 9:
             d_prep = torch.empty((n_items, 512), dtype=torch.int16, device=dev)
