@@ -18,7 +18,8 @@ OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVE
 EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile", "fa_strerror", "fa_verify_many",
            "fa_verify_many_dev", "fa_verify_mixed", "fa_polymul_many", "fa_polymul_many_dev", "fa_pkey_len",
            "fa_sig_len", "fa_prepared_key_len", "fa_prepare_keys", "fa_prepare_keys_dev", "fa_verify_many_prepared",
-           "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev"]
+           "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev", "fa_compute_public_keys",
+           "fa_compute_public_keys_dev"]
 
 
 class FaDebug(ctypes.Structure):
@@ -70,6 +71,8 @@ def load_library():
     lib.fa_verify_many_prepared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug), vp]
     lib.fa_hash_to_point_many.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp]
     lib.fa_hash_to_point_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, vp]
+    lib.fa_compute_public_keys.argtypes = [vp, i32, sz, vp, vp, vp]
+    lib.fa_compute_public_keys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     lib.fa_pkey_len.argtypes = [i32]
     lib.fa_pkey_len.restype = sz
     lib.fa_sig_len.argtypes = [i32]
@@ -217,6 +220,17 @@ class Context:
         _check(self.lib.fa_hash_to_point_many(self.handle, logn, count, _ptr(salt), mp, _ptr(off), mlen, _ptr(c)),
                "fa_hash_to_point_many")
         return c
+
+    def compute_public_keys(self, logn, f, g):
+        """keygen::compute_public_key: h = g / f mod (x^n + 1, q) for (count, N) int32 arrays f, g."""
+        f = np.ascontiguousarray(f, np.int32)
+        g = np.ascontiguousarray(g, np.int32)
+        count = f.shape[0]
+        if f.shape != (count, 1 << logn) or g.shape != f.shape:
+            raise ValueError("f/g must be (count, n)")
+        h = np.zeros(f.shape, np.uint16)
+        _check(self.lib.fa_compute_public_keys(self.handle, logn, count, _ptr(f), _ptr(g), _ptr(h)), "fa_compute_public_keys")
+        return h
 
     def verify_mixed(self, logn, pk, pk_off, msg, msg_off, sig, sig_off, norm_policy=NORM_EXACT64):
         logn = np.ascontiguousarray(logn, np.uint8)

@@ -814,6 +814,53 @@ int fa_hash_to_point_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* sa
   return 0;
 }
 
+int fa_compute_public_keys_dev(fa_ctx* ctx, int logn, size_t count, const int32_t* f, const int32_t* g, uint16_t* h,
+                               void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!f || !g || !h || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (!aligned4(f) || !aligned4(g) || ((uintptr_t)h & 1u)) return FA_E_ALIGN;
+  Guard gd(ctx->device);
+  if (gd.err) return gd.err;
+  hipStream_t s = (hipStream_t)stream;
+  const int T = logn - 9;
+  const uint32_t n = (uint32_t)count;
+  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  if (logn == 9)
+    hipLaunchKernelGGL(pubkey_kernel<9>, dim3(grid), dim3(VERIFY_WG), 0, s, f, g, h, n, ctx->d_tw[T], ctx->d_itw[T],
+                       ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+  else
+    hipLaunchKernelGGL(pubkey_kernel<10>, dim3(grid), dim3(VERIFY_WG), 0, s, f, g, h, n, ctx->d_tw[T], ctx->d_itw[T],
+                       ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+  return (int)hipGetLastError();
+}
+
+int fa_compute_public_keys(fa_ctx* ctx, int logn, size_t count, const int32_t* f, const int32_t* g, uint16_t* h)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!f || !g || !h) return FA_E_ARG;
+  Guard gd(ctx->device);
+  if (gd.err) return gd.err;
+  const size_t in_bytes = (count << logn) * 4, out_bytes = (count << logn) * 2;
+  int rc;
+  if ((rc = ctx->h_a.reserve(in_bytes))) return rc;
+  if ((rc = ctx->h_b.reserve(in_bytes))) return rc;
+  if ((rc = ctx->h_c.reserve(out_bytes))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_a.p, f, in_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_b.p, g, in_bytes, hipMemcpyHostToDevice, s));
+  rc = fa_compute_public_keys_dev(ctx, logn, count, (const int32_t*)ctx->h_a.p, (const int32_t*)ctx->h_b.p,
+                                  (uint16_t*)ctx->h_c.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h, ctx->h_c.p, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
 int fa_polymul_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c,
                         void* stream)
 {

@@ -645,6 +645,50 @@ __global__ __launch_bounds__(VERIFY_WG) void sample_kernel(const uint64_t* __res
   }
 }
 
+// ---- public-key derivation h = g / f in Z_q[x]/(x^n+1) (keygen::compute_public_key, keygen.hpp:67-90) ----
+// One wave per key: lift f, g from [-6145, 6143] to [0, q) (keygen.hpp:80-83), forward transforms, pointwise
+// division (polynomial.hpp:119-130; ff_t::inv of 0 is 0, ff.hpp:181-196, as is 0^(q-2)), inverse transform.
+template <int LOGN>
+__global__ __launch_bounds__(VERIFY_WG) void pubkey_kernel(const int32_t* __restrict__ f, const int32_t* __restrict__ g,
+                                                           uint16_t* __restrict__ h, uint32_t count,
+                                                           const Tw* __restrict__ tw, const Tw* __restrict__ itw,
+                                                           const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                           const NttConsts nc)
+{
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, R = G::R;
+  __shared__ TwLds<LOGN> s_tw;
+  __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
+  for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < count; key += gridDim.x * VERIFY_WAVES) {
+    int32_t x[R], y[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      const int32_t fv = f[(size_t)key * N + idxA<LOGN>(lane, m)], gv = g[(size_t)key * N + idxA<LOGN>(lane, m)];
+      x[m] = fv < 0 ? fv + QI : fv;
+      y[m] = gv < 0 ? gv + QI : gv;
+    }
+    ntt_forward2<LOGN>(x, y, T, s_buf[wave], s_buf2[wave], lane);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      const int32_t b = (int32_t)csub((uint32_t)reduce(x[m]), Q);  // canonical NTT(f) element
+      int32_t inv = b;                                            // b^(q-2), q - 2 = 0b10111111111111
+#pragma unroll
+      for (int bit = 12; bit >= 0; bit--) {
+        inv = mulmod(inv, inv);
+        if ((12287 >> bit) & 1) inv = mulmod(inv, b);
+      }
+      x[m] = mulmod(reduce(y[m]), inv);
+    }
+    ntt_inverse<LOGN>(x, T, s_buf[wave], lane, nc);
+#pragma unroll
+    for (int m = 0; m < R; m++) h[(size_t)key * N + idxA<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)x[m], Q);
+  }
+}
+
 // ---- batched negacyclic product c = a*b in Z_q[x]/(x^n+1) (BASELINE.json config 2) ----
 // Same transforms as the verify path: ntt, polynomial::mul, intt (tests/test_ntt.cpp:48-57).
 template <int LOGN>

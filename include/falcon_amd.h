@@ -123,6 +123,14 @@ int fa_hash_to_point_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* sa
 int fa_hash_to_point_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* salt, const uint8_t* msg,
                               const uint64_t* msg_off, uint32_t mlen, uint16_t* c, void* stream);
 
+/* ---- keygen::compute_public_key<N>(f, g, h), keygen.hpp:67-90: h = g * f^-1 in Z_q[x]/(x^n+1) ----
+ * f, g: count*N int32 coefficients in [-6145, 6143] (the range the reference states, keygen.hpp:78-79);
+ * h: count*N uint16, canonical. Where NTT(f) has a zero the quotient element is 0, as ff_t::inv gives
+ * (ff.hpp:181-196); the reference's keygen never publishes such a key. _dev: asynchronous on `stream`. */
+int fa_compute_public_keys(fa_ctx* ctx, int logn, size_t count, const int32_t* f, const int32_t* g, uint16_t* h);
+int fa_compute_public_keys_dev(fa_ctx* ctx, int logn, size_t count, const int32_t* f, const int32_t* g, uint16_t* h,
+                               void* stream);
+
 /* Mixed Falcon-512 / Falcon-1024 batch, host buffers: logn[i] in {9,10}; item i's key, signature and
  * message are pk[pk_off[i]..], sig[sig_off[i]..], msg[msg_off[i]..msg_off[i+1]). The host splits the
  * batch by N and runs one pass per class. */

@@ -9,6 +9,7 @@
 //   falcon::prepared_keys<N> + verify_many<N>(count, keys, key_idx, ...)
 //                                                      verification.hpp:20-26   verify with the key kept decoded
 //   falcon::hash_to_point_many<N>(count, salts, ...)   hashing.hpp:16-50
+//   falcon::compute_public_keys<N>(count, f, g, h)     keygen.hpp:67-90
 //
 // Both run on the GPU through the C ABI of falcon_amd.h (libfalcon_amd.so); there is no CPU path
 // in this header. Conventions are the reference's: the caller owns every
@@ -201,6 +202,14 @@ inline void hash_to_point_many(size_t count, const uint8_t* salts, const uint8_t
 {
   const int rc = fa_hash_to_point_many(detail::context(device), detail::logn<N>(), count, salts, msgs, msg_off, (uint32_t)mlen, c);
   if (rc) throw device_error("fa_hash_to_point_many", rc);
+}
+
+// keygen::compute_public_key<N>(f, g, h) (keygen.hpp:67-90) for `count` (f, g) pairs: h = g / f mod (x^N + 1, q).
+template<size_t N>
+inline void compute_public_keys(size_t count, const int32_t* f, const int32_t* g, uint16_t* h, int device = 0)
+{
+  const int rc = fa_compute_public_keys(detail::context(device), detail::logn<N>(), count, f, g, h);
+  if (rc) throw device_error("fa_compute_public_keys", rc);
 }
 
 // falcon.hpp:230-249. `sig` is non-const there too (never written).

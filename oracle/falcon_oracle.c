@@ -185,6 +185,23 @@ void fo_polymul(const uint16_t* a, const uint16_t* b, uint16_t* c, unsigned logn
   fo_intt_inplace(c, logn);
 }
 
+/* compute_public_key<N>, keygen.hpp:67-90: h = g / f, division element-wise in the NTT domain
+ * (polynomial::div, polynomial.hpp:119-130; x / 0 = 0 because ff_t::inv(0) = 0, ff.hpp:181-196). */
+void fo_compute_public_key(const int32_t* f, const int32_t* g, uint16_t* h, unsigned logn)
+{
+  const size_t n = (size_t)1 << logn;
+  uint16_t f_[1024], g_[1024];
+  pthread_once(&g_once, init_tables);
+  for (size_t i = 0; i < n; i++) { /* keygen.hpp:80-83 */
+    f_[i] = (uint16_t)((f[i] < 0) * (int32_t)FO_Q + f[i]);
+    g_[i] = (uint16_t)((g[i] < 0) * (int32_t)FO_Q + g[i]);
+  }
+  fo_ntt_inplace(f_, logn);
+  fo_ntt_inplace(g_, logn);
+  for (size_t i = 0; i < n; i++) h[i] = ff_mul(g_[i], ff_inv(f_[i]));
+  fo_intt_inplace(h, logn);
+}
+
 /* Schoolbook negacyclic product with plain % arithmetic: independent check of the NTT path
  * (not in the reference; used by tests to pin N=1024, which has no golden vector). */
 void fo_polymul_schoolbook(const uint16_t* a, const uint16_t* b, uint16_t* c, unsigned logn)

@@ -68,6 +68,9 @@ class Oracle:
         for f in (lib.fo_ntt, lib.fo_intt):
             f.argtypes = [ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint]
             f.restype = None
+        lib.fo_compute_public_key.argtypes = [ctypes.POINTER(ctypes.c_int32)] * 2 + [ctypes.POINTER(ctypes.c_uint16),
+                                                                                    ctypes.c_uint]
+        lib.fo_compute_public_key.restype = None
         for f in (lib.fo_polymul, lib.fo_polymul_schoolbook):
             f.argtypes = [ctypes.POINTER(ctypes.c_uint16)] * 3 + [ctypes.c_uint]
             f.restype = None
@@ -115,6 +118,13 @@ class Oracle:
         f = self.lib.fo_polymul_schoolbook if schoolbook else self.lib.fo_polymul
         f(_p(a, ctypes.c_uint16), _p(b, ctypes.c_uint16), _p(c, ctypes.c_uint16), logn)
         return c
+
+    def compute_public_key(self, logn, f, g):
+        f = np.ascontiguousarray(f, np.int32)
+        g = np.ascontiguousarray(g, np.int32)
+        h = np.zeros(1 << logn, np.uint16)
+        self.lib.fo_compute_public_key(_p(f, ctypes.c_int32), _p(g, ctypes.c_int32), _p(h, ctypes.c_uint16), logn)
+        return h
 
     def verify(self, logn, pk, msg, sig):
         """One item. Returns (flags, debug record): flags bit0 = exact64 accept, bit1 = wrap32 accept."""

@@ -200,3 +200,29 @@ def test_hash_to_point_many(oracle, logn):
         np.testing.assert_array_equal(c.hash_to_point_many(logn, salt[np.array(lens) == 32], fixed), want[np.array(lens) == 32])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_compute_public_keys(ctx, oracle, logn):
+    """keygen::compute_public_key (keygen.hpp:67-90) batched: equal to the oracle, including the full coefficient
+    range [-6145, 6143] and an f with zeros in the NTT domain (division by zero yields 0)."""
+    n = 1 << logn
+    rng = np.random.default_rng(7 + logn)
+    f = rng.integers(-60, 61, (130, n)).astype(np.int32)
+    g = rng.integers(-60, 61, (130, n)).astype(np.int32)
+    f[1] = rng.integers(-6145, 6144, n)
+    g[1] = rng.integers(-6145, 6144, n)
+    f[2] = 0
+    f[2, 0] = 1          # f = 1: h = g
+    f[3] = 0             # f = 0: every quotient element is 0
+    f[4] = 0
+    f[4, 0], f[4, n // 2] = 1, 1   # 1 + x^(n/2): zero at half of the NTT points
+    h = ctx.compute_public_keys(logn, f, g)
+    want = np.stack([oracle.compute_public_key(logn, f[i], g[i]) for i in range(f.shape[0])])
+    np.testing.assert_array_equal(h, want)
+    assert h[2].tolist() == (g[2] % 12289).tolist() and not h[3].any()
+    # h * f == g through the GPU product for the invertible keys
+    fq = (f % 12289).astype(np.uint16)
+    inv = np.array([not (oracle.ntt(fq[i], logn) == 0).any() for i in range(f.shape[0])])
+    prod = ctx.polymul_many(logn, h, fq)
+    np.testing.assert_array_equal(prod[inv], (g % 12289).astype(np.uint16)[inv])

@@ -205,3 +205,20 @@ def test_variable_length_messages(oracle, corpus):
     f1, _ = oracle.verify_many(9, pk, msg, sig)
     f2, _ = oracle.verify_many(9, pk, flat, sig, msg_off=off)
     assert (f1 == 3).all() and (f2 == 3).all()
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_compute_public_key(oracle, logn):
+    """keygen::compute_public_key (keygen.hpp:67-90): h * f == g, checked with the independent schoolbook product
+    (what tests/test_keygen.cpp asserts about a generated key's h, restated for arbitrary small f, g)."""
+    n = 1 << logn
+    rng = np.random.default_rng(logn + 100)
+    for _ in range(3):
+        f = rng.integers(-40, 41, n).astype(np.int32)
+        g = rng.integers(-40, 41, n).astype(np.int32)
+        h = oracle.compute_public_key(logn, f, g)
+        assert h.max() < Q
+        fq = (f % Q).astype(np.uint16)
+        if (oracle.ntt(fq, logn) == 0).any():
+            continue  # not invertible: the reference's keygen would retry
+        assert oracle.polymul(h, fq, logn, schoolbook=True).tolist() == (g % Q).tolist()
