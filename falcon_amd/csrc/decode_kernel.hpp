@@ -339,13 +339,11 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       uint4* tile = (uint4*)(s2 + s2_tile_offset<LOGN>(slot0, (uint32_t)ch * DF_CH));
-#ifndef FA_DEC_NOSTORE
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const uint32_t r = 16u * t + (lane >> 2);  // row, piece lane & 3
         if (slot0 + r < count) tile[64u * t + lane] = *(const uint4*)(outb + r * DF_OUT + (lane & 3u) * 4u);
       }
-#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

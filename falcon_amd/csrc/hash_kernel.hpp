@@ -122,8 +122,11 @@ constexpr int HASH_WG = 256;
 // mlen at msg + item*mlen when msg_off == nullptr, else msg + msg_off[item] with length
 // msg_off[item+1] - msg_off[item] (may differ per lane: the absorb loop diverges, the squeeze
 // loop does not). idx (nullable) maps output slot -> item.
+// Register budget: the sponge (50 VGPRs), the rho/pi copy and the theta temporaries want about 150 VGPRs =
+// three waves per SIMD. Asking for four (128 VGPRs) makes hipcc spill 20 registers and costs 9 % (measured);
+// the kernel is VALU-bound at three.
 #ifndef FA_HASH_WAVES
-#define FA_HASH_WAVES 4
+#define FA_HASH_WAVES 3
 #endif
 __global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
                                                        const uint8_t* __restrict__ msg,
