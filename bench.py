@@ -224,6 +224,21 @@ def main():
             "verifies_per_s": ne / dt, "items": ne, "malformed_share": float((kinds != 0).mean()),
             "accepted_fraction": float(e_acc.float().mean().item()),
             "accept_mismatches_vs_oracle_first_16384": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum())}
+        # mixed Falcon-512 + Falcon-1024 batch (BASELINE.json configs[4], one GPU's share): the batch is split by N
+        # and runs as one pass per class; 2^18 items of each class here
+        if logn == 9:
+            def step_mixed():
+                ctx.verify_many_dev(9, ne, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
+                                    d_acc.data_ptr(), stream=stream)
+                step1024()
+            step_mixed()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step_mixed()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            extras["mixed_512_1024"] = {"verifies_per_s": 2 * ne / dt, "items": 2 * ne, "share_1024": 0.5}
         del e_pk, e_msg, e_sig, e_acc
         # host-buffer entry point (fa_verify_many: H2D staging + kernels + D2H), pageable numpy memory: the
         # PCIe-inclusive rate that DESIGN.md section 7 quotes; never the headline value

@@ -226,3 +226,34 @@ def test_compute_public_keys(ctx, oracle, logn):
     inv = np.array([not (oracle.ntt(fq[i], logn) == 0).any() for i in range(f.shape[0])])
     prod = ctx.polymul_many(logn, h, fq)
     np.testing.assert_array_equal(prod[inv], (g % 12289).astype(np.uint16)[inv])
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_fuzz_random_bytes(ctx, oracle, corpus, logn):
+    """Differential fuzz (the shape of tests/test_encoding.cpp:243-288, which feeds random bytes to the
+    decompressor): random keys and signatures with right and wrong headers, sparse random bodies (long zero runs:
+    the k >= 8 window rule) and single-bit damage to valid items anywhere in key, salt or body."""
+    rng = np.random.default_rng(2024 + logn)
+    n = 1500
+    pk, msg, sig, _ = corpus.generate(logn, n, seed=808 + logn)
+    third = n // 3
+    # (a) fully random records, headers right three times out of four
+    pk[:third] = rng.integers(0, 256, pk[:third].shape, dtype=np.uint8)
+    sig[:third] = rng.integers(0, 256, sig[:third].shape, dtype=np.uint8)
+    pk[:third, 0] = np.where(rng.random(third) < 0.75, logn, pk[:third, 0])
+    sig[:third, 0] = np.where(rng.random(third) < 0.75, 0x30 | logn, sig[:third, 0])
+    # (b) sparse bodies: mostly zero bits, so unary runs of 8 and more occur all the time
+    body = (rng.random((third, sig.shape[1] - 41, 8)) < 0.12)
+    sig[third:2 * third, 41:] = np.packbits(body, axis=2)[:, :, 0]
+    # (c) one flipped bit somewhere in a valid key or signature
+    for i in range(2 * third, n):
+        if rng.random() < 0.5:
+            pk[i, rng.integers(0, pk.shape[1])] ^= 1 << rng.integers(0, 8)
+        else:
+            sig[i, rng.integers(0, sig.shape[1])] ^= 1 << rng.integers(0, 8)
+    flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
+    acc, gdbg = ctx.verify_many(logn, pk, msg, sig, debug=True)
+    _compare_debug(logn, flags, odbg, acc, gdbg)
+    accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)
+    np.testing.assert_array_equal(accw, (flags >> 1) & 1)
+    assert len(set(odbg["status"].tolist())) >= 4  # the fuzz reaches several outcomes
