@@ -129,7 +129,7 @@ struct fa_ctx {
   hipStream_t stream = nullptr;  // private stream for the host-buffer entry points
   hipStream_t aux = nullptr;     // decode kernels run here, beside the hash kernel on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool overlap = false;
+  bool overlap = true;
   Tw* d_tw[2] = { nullptr, nullptr };
   Tw* d_itw[2] = { nullptr, nullptr };
   Tw* d_twc[2] = { nullptr, nullptr };
@@ -209,22 +209,25 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
       hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
                          slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2);
     });
-  } else {  // fast LDS-staged decoder, then the generic one on the items that met the k >= 8 rule
+  } else {  // fast decoder, then the generic one on the items it queued (those that met the k >= 8 rule)
     if ((rc = ctx->slow_count.reserve(4))) return rc;
     if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
     uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
-    // The decoder is latency-bound and the hash kernel issue-bound, and neither depends on the other:
-    // they run side by side on two streams and join before the verify kernel.
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
+    rc = timed(ctx, s, 0, [&] {
+      hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
+                         d_st2, d_cnt, d_list);
+    });
+    if (rc) return rc;
+    // The fix-up pass is one lane per queued item: a few hundred latency-bound waves at most. It runs on
+    // the context's second stream beside the (VALU-bound) hash kernel and joins before the verify kernel.
     hipStream_t ds = ctx->overlap ? ctx->aux : s;
     if (ctx->overlap) {
       HIP_TRY(hipEventRecord(ctx->ev_fork, s));
       HIP_TRY(hipStreamWaitEvent(ds, ctx->ev_fork, 0));
     }
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, ds));
     rc = timed(ctx, ds, 0, [&] {
-      hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, ds, sig, slots, d_s2, d_sqn,
-                         d_st2, d_cnt, d_list);
       hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, ds, sig,
                          (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2);
     });

@@ -39,12 +39,13 @@ __host__ __device__ __forceinline__ size_t s2_tile_offset(uint32_t slot, uint32_
 template <int LOGN>
 __host__ __device__ __forceinline__ size_t s2_tile_elems(size_t slots) { return ((slots + 63u) / 64u * 64u) << LOGN; }
 
-// MSB-first bit reader over the signature body (bytes 41..siglen-1), fed by aligned dwords.
+// MSB-first bit reader over the signature body (bytes 41..siglen-1), fed by aligned 16-byte loads.
 struct BitReader {
-  const uint32_t* base;  // aligned dword holding body byte 0
-  uint32_t al;           // body byte 0 sits at byte `al` of base[0]
+  const uint4* base;     // 16-byte aligned address at or below body byte 0
+  uint32_t al;           // body byte 0 sits at byte `al` (0..15) of base[0]
   int32_t body_bytes;    // siglen - 41
-  int32_t next;          // next dword index to fetch
+  int32_t next;          // next dword index (from base) to hand out
+  uint4 cache;           // base[next >> 2] while (next & 3) != 0
   uint64_t buf;          // MSB-aligned bit buffer
   int32_t nbits;         // valid bits in buf
 
@@ -54,10 +55,13 @@ struct BitReader {
     const int32_t first = 4 * next - (int32_t)al;
     uint32_t w = 0u;
     if (first < body_bytes) {
-      w = __builtin_bswap32(base[next]);  // byte k of the dword -> bits 31-8k .. 24-8k
+      if ((next & 3) == 0 || first <= 0) cache = base[next >> 2];  // never a piece that lies wholly past the row
+      const uint32_t sel = (uint32_t)next & 3u;
+      const uint32_t raw = sel == 0u ? cache.x : sel == 1u ? cache.y : sel == 2u ? cache.z : cache.w;
+      w = __builtin_bswap32(raw);  // byte k of the dword -> bits 31-8k .. 24-8k
       const int32_t valid = body_bytes - first;  // > 0
       if (valid < 4) w &= ~0u << (8 * (4 - valid));
-      if (first < 0) w &= ~0u >> (8 * (-first));  // bytes before the body (only for next == 0)
+      if (first < 0) w &= ~0u >> (8 * (-first));  // bytes before the body (only for the first dword handed out)
     }
     next++;
     return w;
@@ -65,13 +69,13 @@ struct BitReader {
 
   __device__ __forceinline__ void init(const uint8_t* body, int32_t nbytes)
   {
-    al = (uint32_t)((uintptr_t)body & 3u);
-    base = (const uint32_t*)(body - al);
+    al = (uint32_t)((uintptr_t)body & 15u);
+    base = (const uint4*)(body - al);
     body_bytes = nbytes;
-    next = 0;
+    next = (int32_t)(al >> 2);  // the dword that holds body byte 0
     const uint32_t w0 = fetch();
-    buf = (uint64_t)w0 << (32 + 8 * al);
-    nbits = 32 - 8 * (int32_t)al;
+    buf = (uint64_t)w0 << (32 + 8 * (al & 3u));
+    nbits = 32 - 8 * (int32_t)(al & 3u);
     refill();
   }
 
@@ -93,10 +97,11 @@ struct BitReader {
   }
 };
 
-// Generic decoder (every rule, including the k >= 8 windows). sig rows -> s2 (u16, lifted, tiled
-// layout), sqn[o] = sum s2^2, st[o]. idx (nullable) maps slot -> item; outputs go to
-// index o = slot, or o = item when `scatter` (the fix-up pass behind decode_fast_kernel). The number
-// of slots is min(count, *dcount) when dcount is given (a device-side list length).
+// Generic decoder (every rule, including the k >= 8 windows), one signature per lane. sig rows -> s2 (u16,
+// lifted, tiled layout, written 8 coefficients = 16 bytes at a time), sqn[o] = sum s2^2, st[o]. idx
+// (nullable) maps slot -> item; outputs go to index o = slot, or o = item when `scatter` (the fix-up pass
+// behind decode_fast_kernel). The number of slots is min(count, *dcount) when dcount is given (a
+// device-side list length). For an item that fails, the s2 row is left unspecified (nothing reads it).
 template <int LOGN>
 __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __restrict__ sig,
                                                            const uint32_t* __restrict__ idx, uint32_t count,
@@ -124,41 +129,51 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
   br.init(row + 41, SIGLEN - 41);
   int32_t pos = 8 + 320;  // absolute bit index, decoding.hpp:276-277
   int32_t i = 0;
-  bool failed = false;
+  bool failed = false, stop = false;  // stop: the loop of decoding.hpp:281 has ended
   uint32_t norm = 0u;
 
-  while (i < N && pos < SLEN) {  // decoding.hpp:281
-    br.refill();
-    const uint32_t top = br.peek32();
-    const uint32_t sign = top >> 31;
-    uint32_t mag = (top >> 24) & 0x7fu;
-    const uint32_t k = min((uint32_t)__builtin_clz((top << 8) | 0x00800000u), 8u);  // zeros in the 8-bit window
-    if (k < 8) {  // decoding.hpp:297-299
-      mag += k << 7;
-      br.skip(9 + (int32_t)k);
-      pos += 9 + (int32_t)k;
-    } else {  // decoding.hpp:300-320: skip whole windows until one holds a 1 or the stream ends
-      br.skip(16);
-      pos += 16;
-      while (pos < SLEN) {
-        br.refill();
-        const int32_t ebits = min(8, SLEN - pos);
-        const uint32_t t = br.peek32() >> (32 - ebits);
-        br.skip(ebits);
-        pos += ebits;
-        if (t != 0u) break;
-      }
+  for (int g = 0; g < N / 8 && !stop; g++) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      v[j] = 0u;
+      stop |= pos >= SLEN;  // decoding.hpp:281
+      if (stop) continue;
       br.refill();
-      br.skip(1);  // decoding.hpp:335
-      pos += 1;
+      const uint32_t top = br.peek32();
+      const uint32_t sign = top >> 31;
+      uint32_t mag = (top >> 24) & 0x7fu;
+      const uint32_t k = min((uint32_t)__builtin_clz((top << 8) | 0x00800000u), 8u);  // zeros in the 8-bit window
+      if (k < 8) {  // decoding.hpp:297-299
+        mag += k << 7;
+        br.skip(9 + (int32_t)k);
+        pos += 9 + (int32_t)k;
+      } else {  // decoding.hpp:300-320: skip whole windows until one holds a 1 or the stream ends
+        br.skip(16);
+        pos += 16;
+        while (pos < SLEN) {
+          br.refill();
+          const int32_t ebits = min(8, SLEN - pos);
+          const uint32_t t = br.peek32() >> (32 - ebits);
+          br.skip(ebits);
+          pos += ebits;
+          if (t != 0u) break;
+        }
+        br.refill();
+        br.skip(1);  // decoding.hpp:335
+        pos += 1;
+      }
+      if (sign && mag == 0u) {  // decoding.hpp:327-330
+        failed = true;
+        stop = true;
+        continue;
+      }
+      v[j] = sign ? Q - mag : mag;
+      norm += mag * mag;
+      i++;
     }
-    if (sign && mag == 0u) {  // decoding.hpp:327-330
-      failed = true;
-      break;
-    }
-    s2[s2_tile_offset<LOGN>(slot, (uint32_t)i)] = (uint16_t)(sign ? Q - mag : mag);
-    norm += mag * mag;
-    i++;
+    *(uint4*)(s2 + s2_tile_offset<LOGN>(slot, 8u * (uint32_t)g)) =
+      make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
   }
 
   failed |= (pos >= SLEN) | (i < N);  // decoding.hpp:340

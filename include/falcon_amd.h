@@ -46,7 +46,7 @@ extern "C" {
 #define FA_OPT_HASH_BLOCKS_512 2 /* SHAKE256 blocks squeezed per item up front, default 9 */
 #define FA_OPT_HASH_BLOCKS_1024 3 /* default 17; items needing more are re-hashed with twice as many */
 #define FA_OPT_PROFILE 4         /* 1: record HIP events around every kernel (see fa_get_profile) */
-#define FA_OPT_OVERLAP 5         /* 1: decode kernels run on a second stream beside the hash kernel (default 0: no gain measured) */
+#define FA_OPT_OVERLAP 5         /* 1 (default): the decoder's fix-up pass runs on a second stream beside the hash kernel */
 
 typedef struct fa_ctx fa_ctx;
 
