@@ -242,8 +242,8 @@ __device__ __forceinline__ void ntt_forward2(int32_t (&x)[Geo<LOGN>::R], int32_t
   ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(y, T.fC, lane);
 }
 
-// x: in [0, q], phase-C layout (bit-reversed order) -> coefficients in phase-A layout, each in
-// [0, q], already multiplied by 1/N. Phases C and B are six stages together (bound 64q < 2^19 on
+// x: in (-q/60, q + q/60) (mulmod_lazy), phase-C layout (bit-reversed order) -> coefficients in phase-A
+// layout, each in [0, q], already multiplied by 1/N. Phases C and B are six stages together (bound 64q < 2^19 on
 // the differences fed to shoup), so one reduction of the sums after phase B is enough.
 template <int LOGN>
 __device__ __forceinline__ void ntt_inverse(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
@@ -332,13 +332,15 @@ __device__ __forceinline__ void unpack_pkey(const uint32_t (&pkw)[Geo<LOGN>::PKD
 #pragma unroll
   for (int t = 0; t < G::PKDW; t++) pkb[t * 64 + lane] = pkw[t];
   wave_lds_sync();
+  // Coefficient m*64 + lane starts at bit (pal + 1)*8 + 14*lane + 896*m: 896 bits are 28 dwords, so every m has the
+  // same shift and a dword index 28 apart -- one address and one shift per item, immediate offsets after that.
+  const uint32_t bit0 = (pal + 1u) * 8u + 14u * lane;
+  const uint32_t* src = pkb + (bit0 >> 5);
+  const uint32_t sh = bit0 & 31u;
+  static_assert(14 * 64 == 28 * 32 && ((3 + 1) * 8 + 14 * (Geo<LOGN>::N - 1)) / 32 + 1 < Geo<LOGN>::PKDW * 64, "pk row layout");
 #pragma unroll
-  for (int m = 0; m < G::R; m++) {
-    const uint32_t bit = (pal + 1u) * 8u + 14u * idxA<LOGN>(lane, m);
-    const uint32_t dw = bit >> 5, sh = bit & 31u;
-    const uint32_t lo = pkb[dw], hi = pkb[min(dw + 1u, (uint32_t)G::PKDW * 64u - 1u)];
-    y[m] = (int32_t)(__builtin_amdgcn_alignbit(hi, lo, sh) & 0x3fffu);  // <= 16383, reduced by the transform itself
-  }
+  for (int m = 0; m < G::R; m++)
+    y[m] = (int32_t)(__builtin_amdgcn_alignbit(src[28 * m + 1], src[28 * m], sh) & 0x3fffu);  // <= 16383, reduced by the transform itself
 }
 
 // Prepared keys: NTT(h) of a public key, canonical u16, in the order the verify kernel consumes it
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
 #pragma unroll
         for (int m = 0; m < R; m++) {  // NTT(h), canonical, already in this lane's phase-C positions
           const uint32_t hv = (cur.hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
-          x[m] = mulmod(reduce(x[m]), (int32_t)hv);  // polynomial.hpp:99-110
+          x[m] = mulmod_lazy(x[m], (int32_t)hv);  // polynomial.hpp:99-110; |x| <= 11q, hv < q
         }
       } else {
         // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
           ntt_forward<LOGN>(x, T, buf, lane);
         }
 #pragma unroll
-        for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));  // polynomial.hpp:99-110
+        for (int m = 0; m < R; m++) x[m] = mulmod_lazy(reduce(x[m]), y[m]);  // polynomial.hpp:99-110; |y| <= 16383 + 10q
       }
       ntt_inverse<LOGN>(x, T, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
 

@@ -73,4 +73,16 @@ __device__ __forceinline__ int32_t mulmod(int32_t a, int32_t b)
   return (int32_t)csub((uint32_t)mad_i24((int32_t)qh, -QI, (int32_t)p), Q);
 }
 
+// |a * b| < 2^31 (e.g. a in [0, q], |b| < 2^17)  ->  (a*b) mod q as a value in (-q/60, q + q/60): the signed
+// Barrett quotient mulhi(p, round(2^32/q)) is off by at most one when p/q is within 2^31 * 0.04 / 2^32 < 1/50
+// of an integer. Three instructions; good enough as input of the inverse transform, whose first Shoup
+// multiplication and reductions take any |x| < 2^19.
+__device__ __forceinline__ int32_t mulmod_lazy(int32_t a, int32_t b)
+{
+  const int32_t p = a * b;
+  int32_t r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__mulhi(p, RQ32)), "s"(-QI), "v"(p));
+  return r;
+}
+
 }  // namespace fa
