@@ -12,14 +12,14 @@ LIB_PATH = os.environ.get("FALCON_AMD_LIB") or os.path.join(_HERE, "libfalcon_am
 
 NORM_EXACT64, NORM_WRAP32 = 0, 1
 ST_OK, ST_BAD_PK_HEADER, ST_BAD_SIG_HEADER, ST_BAD_ENCODING, ST_NORM_TOO_LARGE = range(5)
-OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVERLAP = 1, 2, 3, 4, 5
+OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVERLAP, OPT_HOST_CHUNK_ITEMS, OPT_HOST_THREADS = 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/falcon_amd.h declares
 EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile", "fa_strerror", "fa_verify_many",
            "fa_verify_many_dev", "fa_verify_mixed", "fa_polymul_many", "fa_polymul_many_dev", "fa_pkey_len",
            "fa_sig_len", "fa_prepared_key_len", "fa_prepare_keys", "fa_prepare_keys_dev", "fa_verify_many_prepared",
            "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev", "fa_compute_public_keys",
-           "fa_compute_public_keys_dev"]
+           "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister"]
 
 
 class FaDebug(ctypes.Structure):
@@ -73,6 +73,12 @@ def load_library():
     lib.fa_hash_to_point_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, vp]
     lib.fa_compute_public_keys.argtypes = [vp, i32, sz, vp, vp, vp]
     lib.fa_compute_public_keys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_host_alloc.argtypes = [sz]
+    lib.fa_host_alloc.restype = vp
+    lib.fa_host_free.argtypes = [vp]
+    lib.fa_host_free.restype = None
+    lib.fa_host_register.argtypes = [vp, sz]
+    lib.fa_host_unregister.argtypes = [vp]
     lib.fa_pkey_len.argtypes = [i32]
     lib.fa_pkey_len.restype = sz
     lib.fa_sig_len.argtypes = [i32]
@@ -89,6 +95,31 @@ def _check(rc, what):
 
 def _ptr(a):
     return a.ctypes.data if a is not None else None
+
+
+class PinnedArray:
+    """A numpy array in pinned host memory (fa_host_alloc); `.array` is the view, close() frees it."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.lib = load_library()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.lib.fa_host_alloc(max(nbytes, 1))
+        if not self.ptr:
+            raise FalconAmdError(f"fa_host_alloc({nbytes}) failed")
+        buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.fa_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -121,7 +152,7 @@ class Context:
         return {k: getattr(p, k) for k, _ in FaProfile._fields_}
 
     # ---- host-buffer entry points (numpy arrays) ----
-    def verify_many(self, logn, pk, msg, sig, msg_off=None, norm_policy=NORM_EXACT64, debug=False):
+    def verify_many(self, logn, pk, msg, sig, msg_off=None, norm_policy=NORM_EXACT64, debug=False, accept_out=None):
         """pk (count, pklen) u8, sig (count, siglen) u8; msg (count, mlen) u8, or flat bytes with
         msg_off (count+1) u64. Returns accept (count,) u8 and, with debug=True, a dict of intermediates."""
         n = 1 << logn
@@ -140,7 +171,9 @@ class Context:
             if off.shape != (count + 1,):
                 raise ValueError("msg_off must hold count+1 offsets")
             mlen = 0
-        accept = np.zeros(count, np.uint8)
+        accept = np.zeros(count, np.uint8) if accept_out is None else accept_out  # e.g. a PinnedArray's view
+        if accept.dtype != np.uint8 or accept.shape != (count,) or not accept.flags.c_contiguous:
+            raise ValueError("accept_out must be a contiguous (count,) uint8 array")
         dbg = None
         out = None
         if debug:

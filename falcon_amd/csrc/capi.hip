@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/falcon_amd.h"
@@ -110,6 +111,72 @@ struct DevBuf {
   }
 };
 
+struct PinBuf {  // pinned host staging memory
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return 0;
+    if (p) HIP_TRY(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return 0;
+  }
+  void release()
+  {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+bool is_pinned(const void* p)
+{
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain pageable memory is unknown to the runtime: not an error here
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// Host-to-device copy of `bytes` on stream `xs`. Pinned caller memory goes out as one asynchronous copy.
+// Pageable memory is staged through `pin` by `threads` host threads, 4 MiB pieces round-robin: a thread
+// copies a piece into the pinned buffer and enqueues its DMA itself, so the host-side copying of one piece
+// overlaps the DMA of the others (the runtime's own pageable path does this on a single thread and reaches
+// about half the link's rate). Returns once everything is enqueued; `pin` is busy until `xs` has run.
+int h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t xs, PinBuf& pin, unsigned threads)
+{
+  constexpr size_t PIECE = (size_t)4 << 20;
+  if (bytes == 0) return 0;
+  if (bytes < PIECE || threads == 0 || is_pinned(src)) return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, xs);
+  int rc = pin.reserve(bytes);
+  if (rc) return rc;
+  const size_t pieces = (bytes + PIECE - 1) / PIECE;
+  const unsigned nt = (unsigned)std::min<size_t>(threads, pieces);
+  std::vector<int> err(nt, 0);
+  auto work = [&](unsigned t) {
+    if (hipSetDevice(device) != hipSuccess) {
+      err[t] = (int)hipErrorInvalidDevice;
+      return;
+    }
+    for (size_t i = t; i < pieces && !err[t]; i += nt) {
+      const size_t o = i * PIECE, len = std::min(PIECE, bytes - o);
+      std::memcpy((uint8_t*)pin.p + o, (const uint8_t*)src + o, len);
+      err[t] = (int)hipMemcpyAsync((uint8_t*)dst + o, (const uint8_t*)pin.p + o, len, hipMemcpyHostToDevice, xs);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  for (int e : err)
+    if (e) return e;
+  return 0;
+}
+
 struct KeySrc {  // where a pass takes its public keys from
   const uint8_t* pk = nullptr;         // packed keys, one per item
   const uint16_t* prepared = nullptr;  // or prepared keys (prepare_keys_kernel) ...
@@ -128,7 +195,10 @@ struct fa_ctx {
   int num_cu = 256;
   hipStream_t stream = nullptr;  // private stream for the host-buffer entry points
   hipStream_t aux = nullptr;     // decode kernels run here, beside the hash kernel on the caller's stream
+  hipStream_t copy = nullptr;    // host-buffer entry points: H2D staging of the next sub-batch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_ready[2] = { nullptr, nullptr };  // staging set k is filled
+  uint32_t host_chunk = 1u << 17;  // items per sub-batch of the host-buffer pipeline
   bool overlap = true;
   Tw* d_tw[2] = { nullptr, nullptr };
   Tw* d_itw[2] = { nullptr, nullptr };
@@ -140,8 +210,13 @@ struct fa_ctx {
   bool profile = false;
   // pipeline workspace (per chunk)
   DevBuf hraw, s2, sqn, st2, retry_count, retry_list, slow_count, slow_list;
-  // staging for the host-buffer entry points
-  DevBuf h_pk, h_sig, h_msg, h_off, h_kidx, h_accept, h_dbg[6], h_a, h_b, h_c;
+  // staging for the host-buffer entry points; the verify pipeline double-buffers its per-item inputs
+  struct HostStage {
+    DevBuf pk, sig, msg, off, kidx, accept, dbg[6];
+    PinBuf pin_pk, pin_sig, pin_msg;  // pinned staging for pageable caller memory
+  } hs[2];
+  uint32_t host_threads = 6;  // host threads staging pageable memory (0: leave it to the runtime)
+  DevBuf h_pk, h_sig, h_msg, h_off, h_a, h_b, h_c;
   std::vector<EventPair> events;
   uint32_t retried = 0;
 };
@@ -189,7 +264,6 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
              const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, uint32_t nblk, int policy, uint8_t* accept,
              const DebugOut& dbg, bool debug, uint32_t item_base)
 {
-  using G = Geo<LOGN>;
   constexpr int T = LOGN - 9;
   constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
   if (slots == 0) return 0;
@@ -281,19 +355,28 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   return rc;
 }
 
-template <int LOGN>
-int verify_dev(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
-               const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+DebugOut debug_out(const fa_debug* dbgp, bool& debug)
 {
-  using G = Geo<LOGN>;
-  constexpr int T = LOGN - 9;
-  constexpr size_t SIGLEN = LOGN == 9 ? 666 : 1280;
   DebugOut dbg{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  bool debug = false;
+  debug = false;
   if (dbgp) {
     dbg = DebugOut{ dbgp->c, dbgp->s2, dbgp->s1, (unsigned long long*)dbgp->norm_exact, dbgp->norm_wrap32, dbgp->status };
     debug = dbg.c || dbg.s2 || dbg.s1 || dbg.norm_exact || dbg.norm_wrap32 || dbg.status;
   }
+  return dbg;
+}
+
+// Main passes of a batch, chunk by chunk, enqueued on `s` without synchronising. Items whose rejection
+// sampling ran out of squeezed blocks are left in ctx->retry_list for verify_finish.
+template <int LOGN>
+int verify_enqueue(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+                   const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+{
+  using G = Geo<LOGN>;
+  constexpr int T = LOGN - 9;
+  constexpr size_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  bool debug;
+  const DebugOut dbg = debug_out(dbgp, debug);
   int rc;
   if ((rc = ctx->retry_count.reserve(4))) return rc;
   if ((rc = ctx->retry_list.reserve(std::max<size_t>(count, 1) * 4))) return rc;
@@ -316,9 +399,20 @@ int verify_dev(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg
                         accept + c0, d, debug, (uint32_t)c0);
     if (rc) return rc;
   }
+  return 0;
+}
 
-  // Items whose rejection sampling ran out of squeezed blocks (probability ~1e-25 / ~1e-13 per item
-  // at the default block counts) are re-hashed with twice as many blocks until none is left.
+// Synchronises `s` and re-hashes the items verify_enqueue left over (probability ~1e-25 / ~1e-13 per item
+// at the default block counts) with twice as many blocks until none is left. Same arguments as the
+// verify_enqueue call it completes.
+template <int LOGN>
+int verify_finish(fa_ctx* ctx, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+                  const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+{
+  constexpr int T = LOGN - 9;
+  bool debug;
+  const DebugOut dbg = debug_out(dbgp, debug);
+  int rc;
   uint32_t nblk = ctx->hash_blocks[T];
   for (;;) {
     uint32_t pending = 0;
@@ -341,6 +435,14 @@ int verify_dev(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg
     if (rc) return rc;
   }
   return 0;
+}
+
+template <int LOGN>
+int verify_dev(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+               const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+{
+  const int rc = verify_enqueue<LOGN>(ctx, count, keys, msg, msg_off, mlen, sig, policy, accept, dbgp, s);
+  return rc ? rc : verify_finish<LOGN>(ctx, keys, msg, msg_off, mlen, sig, policy, accept, dbgp, s);
 }
 
 // hash_to_point for `count` (salt, message) pairs: SHAKE256 blocks, then rejection sampling; items that need
@@ -451,6 +553,8 @@ int fa_ctx_create(int device, fa_ctx** out)
     ctx->num_cu = prop.multiProcessorCount;
     rc = (int)hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (!rc) rc = (int)hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
+    if (!rc) rc = (int)hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && !rc; k++) rc = (int)hipEventCreateWithFlags(&ctx->ev_ready[k], hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
   }
@@ -482,6 +586,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
   Guard g(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+  if (ctx->copy) (void)hipStreamSynchronize(ctx->copy);
   for (auto& e : ctx->events) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -493,11 +598,21 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
   }
   DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->slow_count, &ctx->slow_list, &ctx->h_pk,
-                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_kidx, &ctx->h_accept, &ctx->h_a, &ctx->h_b, &ctx->h_c };
+                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_a, &ctx->h_b, &ctx->h_c };
   for (DevBuf* b : bufs) b->release();
-  for (DevBuf& b : ctx->h_dbg) b.release();
+  for (auto& st : ctx->hs) {
+    DevBuf* sb[] = { &st.pk, &st.sig, &st.msg, &st.off, &st.kidx, &st.accept };
+    for (DevBuf* b : sb) b->release();
+    for (DevBuf& b : st.dbg) b.release();
+    st.pin_pk.release();
+    st.pin_sig.release();
+    st.pin_msg.release();
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+  if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+  for (hipEvent_t e : ctx->ev_ready)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
@@ -521,6 +636,14 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
       return 0;
     case FA_OPT_OVERLAP:
       ctx->overlap = value != 0;
+      return 0;
+    case FA_OPT_HOST_CHUNK_ITEMS:
+      if (value < 64 || value > (1 << 24)) return FA_E_ARG;
+      ctx->host_chunk = (uint32_t)value;
+      return 0;
+    case FA_OPT_HOST_THREADS:
+      if (value < 0 || value > 64) return FA_E_ARG;
+      ctx->host_threads = (uint32_t)value;
       return 0;
     default:
       return FA_E_ARG;
@@ -639,8 +762,12 @@ int fa_prepare_keys(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, cons
   return 0;
 }
 
-// Host-buffer front end shared by fa_verify_many and fa_verify_many_prepared: stage the inputs, run the
-// device entry point on the context's private stream, copy the outputs back.
+// Host-buffer front end shared by fa_verify_many and fa_verify_many_prepared. The batch is cut into
+// sub-batches of ctx->host_chunk items with two sets of device staging buffers: while the kernels of
+// sub-batch k run on ctx->stream, the inputs of sub-batch k+1 cross the host link on ctx->copy. With
+// pageable caller memory the copy calls block the host thread (the runtime stages them) but still overlap
+// the kernels already enqueued; with pinned memory (fa_host_alloc / fa_host_register) they are asynchronous
+// and the whole call runs at the rate of the host link.
 static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint16_t* prepared, size_t nkeys,
                        const uint32_t* key_idx, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
                        const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
@@ -656,67 +783,146 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
       for (size_t i = 0; i < count; i++)
         if (key_idx[i] >= nkeys) return FA_E_ARG;
   }
+  if (msg_off)
+    for (size_t i = 0; i < count; i++)
+      if (msg_off[i + 1] < msg_off[i]) return FA_E_ARG;
   Guard g(ctx->device);
   if (g.err) return g.err;
   const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);
-  // With offsets only the window [msg_off[0], msg_off[count]) is staged (a shard of a larger batch
-  // passes a window of the global offset array); it lands at byte (first & 3) of the staging buffer
-  // so that the device-side base pointer `h_msg - (first & ~3)` stays 4-byte aligned.
-  const size_t first = msg_off ? (size_t)msg_off[0] : 0;
-  if (msg_off && (size_t)msg_off[count] < first) return FA_E_ARG;
-  const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;
-  const size_t key_bytes = prepared ? nkeys * n * 2 : count * pklen;
-  hipStream_t s = ctx->stream;
+  hipStream_t cs = ctx->stream, xs = ctx->copy;
   int rc;
-  // +8 bytes of slack: the kernels read whole aligned dwords around the last record
-  if ((rc = ctx->h_pk.reserve(key_bytes + 8))) return rc;
-  if ((rc = ctx->h_sig.reserve(count * siglen + 8))) return rc;
-  if ((rc = ctx->h_msg.reserve(msg_bytes + 12))) return rc;
-  if ((rc = ctx->h_accept.reserve(count))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, prepared ? (const void*)prepared : (const void*)pk, key_bytes, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(ctx->h_sig.p, sig, count * siglen, hipMemcpyHostToDevice, s));
-  uint8_t* d_msg_stage = (uint8_t*)ctx->h_msg.p + (first & 3u);
-  if (msg_bytes) HIP_TRY(hipMemcpyAsync(d_msg_stage, msg + first, msg_bytes, hipMemcpyHostToDevice, s));
-  const uint8_t* d_msg = d_msg_stage - first;  // message i starts at d_msg + msg_off[i]
-  const uint64_t* d_off = nullptr;
-  if (msg_off) {
-    if ((rc = ctx->h_off.reserve((count + 1) * 8))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->h_off.p, msg_off, (count + 1) * 8, hipMemcpyHostToDevice, s));
-    d_off = (const uint64_t*)ctx->h_off.p;
+
+  const uint16_t* d_prepared = nullptr;
+  if (prepared) {  // the key table is shared by all sub-batches: staged once, ahead of the first kernel
+    if ((rc = ctx->h_pk.reserve(nkeys * n * 2 + 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, prepared, nkeys * n * 2, hipMemcpyHostToDevice, cs));
+    d_prepared = (const uint16_t*)ctx->h_pk.p;
   }
-  const uint32_t* d_kidx = nullptr;
-  if (prepared && key_idx) {
-    if ((rc = ctx->h_kidx.reserve(count * 4))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->h_kidx.p, key_idx, count * 4, hipMemcpyHostToDevice, s));
-    d_kidx = (const uint32_t*)ctx->h_kidx.p;
-  }
-  fa_debug d{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  const size_t sz[6] = { count * n * 2, count * n * 2, count * n * 2, count * 8, count * 4, count };
-  if (dbg) {
-    void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
-    void** dev[6] = { (void**)&d.c, (void**)&d.s2, (void**)&d.s1, (void**)&d.norm_exact, (void**)&d.norm_wrap32,
-                      (void**)&d.status };
-    for (int i = 0; i < 6; i++) {
-      if (!host[i]) continue;
-      if ((rc = ctx->h_dbg[i].reserve(sz[i]))) return rc;
-      *dev[i] = ctx->h_dbg[i].p;
+
+  struct Sub {  // one sub-batch: its window of the caller's arrays and where it sits on the device
+    size_t c0 = 0, cnt = 0;
+    KeySrc keys;
+    const uint8_t* d_msg = nullptr;
+    const uint64_t* d_off = nullptr;
+    const uint8_t* d_sig = nullptr;
+    uint8_t* d_accept = nullptr;
+    fa_debug d{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t dsz[6] = { 0, 0, 0, 0, 0, 0 };
+  };
+
+  // H2D staging of sub-batch k on the copy stream. +8 / +12 bytes of slack: the kernels read whole aligned
+  // dwords around the last record.
+  auto stage_in = [&](size_t k, Sub& S) -> int {
+    fa_ctx::HostStage& st = ctx->hs[k & 1];
+    S = Sub{};
+    S.c0 = k * (size_t)ctx->host_chunk;
+    S.cnt = std::min<size_t>(ctx->host_chunk, count - S.c0);
+    int r;
+    if ((r = st.sig.reserve(S.cnt * siglen + 8))) return r;
+    if ((r = st.accept.reserve(S.cnt))) return r;
+    if ((r = h2d(ctx->device, st.sig.p, sig + S.c0 * siglen, S.cnt * siglen, xs, st.pin_sig, ctx->host_threads))) return r;
+    S.d_sig = (const uint8_t*)st.sig.p;
+    S.d_accept = (uint8_t*)st.accept.p;
+    if (prepared) {
+      S.keys.prepared = key_idx ? d_prepared : d_prepared + S.c0 * n;  // no index: item i uses key i
+      if (key_idx) {
+        if ((r = st.kidx.reserve(S.cnt * 4))) return r;
+        HIP_TRY(hipMemcpyAsync(st.kidx.p, key_idx + S.c0, S.cnt * 4, hipMemcpyHostToDevice, xs));
+        S.keys.key_idx = (const uint32_t*)st.kidx.p;
+      }
+    } else {
+      if ((r = st.pk.reserve(S.cnt * pklen + 8))) return r;
+      if ((r = h2d(ctx->device, st.pk.p, pk + S.c0 * pklen, S.cnt * pklen, xs, st.pin_pk, ctx->host_threads))) return r;
+      S.keys.pk = (const uint8_t*)st.pk.p;
     }
+    // With offsets only the window [msg_off[c0], msg_off[c0 + cnt]) is staged; it lands at byte (first & 3)
+    // of the staging buffer so that the device-side base pointer `stage - (first & ~3)` stays 4-byte
+    // aligned, and message i is found at d_msg + msg_off[i] with the caller's own offsets.
+    const size_t first = msg_off ? (size_t)msg_off[S.c0] : 0;
+    const size_t msg_bytes = msg_off ? (size_t)msg_off[S.c0 + S.cnt] - first : S.cnt * (size_t)mlen;
+    if ((r = st.msg.reserve(msg_bytes + 12))) return r;
+    uint8_t* stage = (uint8_t*)st.msg.p + (first & 3u);
+    if ((r = h2d(ctx->device, stage, msg_off ? msg + first : msg + S.c0 * (size_t)mlen, msg_bytes, xs, st.pin_msg, ctx->host_threads)))
+      return r;
+    S.d_msg = stage - first;
+    if (msg_off) {
+      if ((r = st.off.reserve((S.cnt + 1) * 8))) return r;
+      HIP_TRY(hipMemcpyAsync(st.off.p, msg_off + S.c0, (S.cnt + 1) * 8, hipMemcpyHostToDevice, xs));
+      S.d_off = (const uint64_t*)st.off.p;
+    }
+    if (dbg) {
+      void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
+      void** dev[6] = { (void**)&S.d.c, (void**)&S.d.s2, (void**)&S.d.s1, (void**)&S.d.norm_exact, (void**)&S.d.norm_wrap32,
+                        (void**)&S.d.status };
+      const size_t sz[6] = { S.cnt * n * 2, S.cnt * n * 2, S.cnt * n * 2, S.cnt * 8, S.cnt * 4, S.cnt };
+      for (int i = 0; i < 6; i++) {
+        if (!host[i]) continue;
+        if ((r = st.dbg[i].reserve(sz[i]))) return r;
+        *dev[i] = st.dbg[i].p;
+        S.dsz[i] = sz[i];
+      }
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_ready[k & 1], xs));
+    return 0;
+  };
+  auto launch = [&](size_t k, const Sub& S) -> int {
+    HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_ready[k & 1], 0));
+    const fa_debug* dp = dbg ? &S.d : nullptr;
+    return logn == 9 ? verify_enqueue<9>(ctx, S.cnt, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs)
+                     : verify_enqueue<10>(ctx, S.cnt, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs);
+  };
+  auto finish = [&](const Sub& S) -> int {
+    const fa_debug* dp = dbg ? &S.d : nullptr;
+    int r = logn == 9 ? verify_finish<9>(ctx, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs)
+                      : verify_finish<10>(ctx, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs);
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(accept + S.c0, S.d_accept, S.cnt, hipMemcpyDeviceToHost, cs));
+    if (dbg) {
+      uint8_t* const host[6] = { (uint8_t*)dbg->c, (uint8_t*)dbg->s2, (uint8_t*)dbg->s1, (uint8_t*)dbg->norm_exact,
+                                 (uint8_t*)dbg->norm_wrap32, (uint8_t*)dbg->status };
+      void* const dev[6] = { S.d.c, S.d.s2, S.d.s1, S.d.norm_exact, S.d.norm_wrap32, S.d.status };
+      const size_t per_item[6] = { n * 2, n * 2, n * 2, 8, 4, 1 };
+      for (int i = 0; i < 6; i++)
+        if (host[i]) HIP_TRY(hipMemcpyAsync(host[i] + S.c0 * per_item[i], dev[i], S.dsz[i], hipMemcpyDeviceToHost, cs));
+    }
+    return 0;
+  };
+
+  // Order per sub-batch k: kernels of k, then the copies of k+1 (they overlap those kernels), then the
+  // synchronising tail of k. finish(k) has synchronised ctx->stream before staging set k & 1 is refilled for
+  // sub-batch k+2, so the sets need no further events.
+  const size_t nsub = (count + ctx->host_chunk - 1) / ctx->host_chunk;
+  Sub cur, nxt;
+  rc = stage_in(0, cur);
+  for (size_t k = 0; !rc && k < nsub; k++) {
+    rc = launch(k, cur);
+    if (!rc && k + 1 < nsub) rc = stage_in(k + 1, nxt);
+    if (!rc) rc = finish(cur);
+    cur = nxt;
   }
-  if (prepared)
-    rc = fa_verify_many_prepared_dev(ctx, logn, count, (const uint16_t*)ctx->h_pk.p, d_kidx, d_msg, d_off, mlen,
-                                     (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
-  else
-    rc = fa_verify_many_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, d_msg, d_off, mlen,
-                            (const uint8_t*)ctx->h_sig.p, norm_policy, (uint8_t*)ctx->h_accept.p, dbg ? &d : nullptr, s);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(accept, ctx->h_accept.p, count, hipMemcpyDeviceToHost, s));
-  if (dbg) {
-    void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
-    for (int i = 0; i < 6; i++)
-      if (host[i]) HIP_TRY(hipMemcpyAsync(host[i], ctx->h_dbg[i].p, sz[i], hipMemcpyDeviceToHost, s));
-  }
-  HIP_TRY(hipStreamSynchronize(s));
-  return 0;
+  const int rs = (int)hipStreamSynchronize(xs), rt = (int)hipStreamSynchronize(cs);  // nothing of the caller's is in flight on return
+  return rc ? rc : rs ? rs : rt;
+}
+
+void* fa_host_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void fa_host_free(void* p)
+{
+  if (p) (void)hipHostFree(p);
+}
+int fa_host_register(void* p, size_t bytes)
+{
+  if (!p || bytes == 0) return FA_E_ARG;
+  return (int)hipHostRegister(p, bytes, hipHostRegisterDefault);
+}
+int fa_host_unregister(void* p)
+{
+  if (!p) return FA_E_ARG;
+  return (int)hipHostUnregister(p);
 }
 
 int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off,

@@ -47,6 +47,8 @@ extern "C" {
 #define FA_OPT_HASH_BLOCKS_1024 3 /* default 17; items needing more are re-hashed with twice as many */
 #define FA_OPT_PROFILE 4         /* 1: record HIP events around every kernel (see fa_get_profile) */
 #define FA_OPT_OVERLAP 5         /* 1 (default): the decoder's fix-up pass runs on a second stream beside the hash kernel */
+#define FA_OPT_HOST_CHUNK_ITEMS 6 /* items per sub-batch of the host-buffer pipeline (copy/compute overlap), default 2^17 */
+#define FA_OPT_HOST_THREADS 7    /* host threads that stage pageable caller memory through pinned buffers, default 6; 0: the runtime's own path */
 
 typedef struct fa_ctx fa_ctx;
 
@@ -78,7 +80,11 @@ const char* fa_strerror(int code);
 /* Batched falcon::verify<N> (falcon.hpp:230-249), host buffers. pk: count*pklen bytes, sig:
  * count*siglen bytes. Messages: msg_off == NULL -> fixed length mlen at msg + i*mlen; else message i
  * is msg[msg_off[i] .. msg_off[i+1]) (count+1 offsets) and mlen is ignored. accept[i] = 1/0 exactly
- * as the reference's bool. Inputs are copied to device storage; callers need not pad them. */
+ * as the reference's bool. Inputs are copied to device storage; callers need not pad them. The batch is
+ * processed in sub-batches of FA_OPT_HOST_CHUNK_ITEMS items, the copies of one overlapping the kernels of
+ * the previous one; the call returns when everything is done. Caller memory may be pageable: it is then
+ * staged through pinned buffers of the context (two sets of one sub-batch each) by FA_OPT_HOST_THREADS host
+ * threads; pinned caller memory (fa_host_alloc / fa_host_register below) is copied from directly. */
 int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
                    const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
                    uint8_t* accept, const fa_debug* dbg);
@@ -145,6 +151,14 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
 int fa_polymul_many(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c);
 int fa_polymul_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c,
                         void* stream);
+
+/* Pinned host memory for the host-buffer entry points (no reference counterpart: the reference never
+ * leaves the CPU). fa_host_alloc returns NULL on failure; fa_host_register pins an existing range
+ * (page-granular, costly: worth it only for buffers that are reused). */
+void* fa_host_alloc(size_t bytes);
+void fa_host_free(void* p);
+int fa_host_register(void* p, size_t bytes);
+int fa_host_unregister(void* p);
 
 /* Record sizes, utils.hpp:9-17 and :39-49. */
 size_t fa_pkey_len(int logn);

@@ -93,6 +93,31 @@ inline fa_ctx* context(int device)
 template<size_t N> constexpr size_t pkey_len() { return 1 + 14 * N / 8; }
 template<size_t N> constexpr size_t sig_len() { return N == 512 ? 666 : 1280; }
 
+// Pinned host memory (fa_host_alloc): batches assembled in it cross the host link without the staging copy
+// that pageable memory (std::vector, new[]) needs. No reference counterpart.
+template<typename T>
+class pinned_buffer
+{
+public:
+  explicit pinned_buffer(size_t count) : size_(count), p_(static_cast<T*>(fa_host_alloc(count > 0 ? count * sizeof(T) : 1)))
+  {
+    if (!p_) throw device_error("fa_host_alloc", FA_E_INTERNAL);
+  }
+  pinned_buffer(const pinned_buffer&) = delete;
+  pinned_buffer& operator=(const pinned_buffer&) = delete;
+  pinned_buffer(pinned_buffer&& o) noexcept : size_(o.size_), p_(o.p_) { o.p_ = nullptr; }
+  ~pinned_buffer() { fa_host_free(p_); }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  size_t size() const { return size_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+
+private:
+  size_t size_;
+  T* p_;
+};
+
 // Batch of `count` independent falcon::verify<N> calls (falcon.hpp:230-249).
 //   pkeys  count * pkey_len<N>() bytes, sigs  count * sig_len<N>() bytes, contiguous records;
 //   msgs   msg_off == nullptr: message i is the mlen bytes at msgs + i*mlen,

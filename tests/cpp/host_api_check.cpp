@@ -6,6 +6,7 @@
 // prints one line of '0'/'1' accept flags from verify_many<N>, a second line from per-item
 // verify<N> calls on the first min(count, 8) items, a third from the prepared-key form, and a fourth from
 // verify_many_sharded<N>.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -50,7 +51,9 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     std::putchar('\n');
   }
   std::vector<uint8_t> acc2(count, 7);
-  falcon::verify_many_sharded<N>(count, pk.data(), msg.data(), mlen, nullptr, sig.data(), acc2.data(), ndev);
+  falcon::pinned_buffer<uint8_t> ppk(pk.size());  // keys from pinned memory, the rest pageable
+  std::copy(pk.begin(), pk.end(), ppk.data());
+  falcon::verify_many_sharded<N>(count, ppk.data(), msg.data(), mlen, nullptr, sig.data(), acc2.data(), ndev);
   for (uint8_t a : acc2) std::putchar('0' + a);
   std::putchar('\n');
   return 0;

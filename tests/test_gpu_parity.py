@@ -257,3 +257,57 @@ def test_fuzz_random_bytes(ctx, oracle, corpus, logn):
     accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)
     np.testing.assert_array_equal(accw, (flags >> 1) & 1)
     assert len(set(odbg["status"].tolist())) >= 4  # the fuzz reaches several outcomes
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_host_pipeline_sub_batches(oracle, corpus, logn):
+    """fa_verify_many / fa_verify_many_prepared cut a host batch into sub-batches whose copies overlap the previous
+    sub-batch's kernels (two staging sets). Small, non-dividing sub-batches exercise every hand-over: ragged message
+    offsets (a window of the offset array per sub-batch), the debug outputs, prepared keys with and without an index,
+    pageable and pinned caller memory."""
+    from falcon_amd import capi
+    c = capi.Context(0)
+    pinned = []
+    try:
+        c.set_option(capi.OPT_HOST_CHUNK_ITEMS, 192)
+        c.set_option(capi.OPT_CHUNK_ITEMS, 128)
+        count = 1000  # 5 full sub-batches and one of 40 items
+        pk, _, sig, _ = corpus.generate(logn, count, seed=91 + logn, malformed_permille=300)
+        rng = np.random.default_rng(5)
+        lens = rng.integers(0, 300, count)
+        lens[:3] = (0, 1, 1024)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        flat = rng.integers(0, 256, int(off[-1]), dtype=np.uint8)
+        flags, odbg = oracle.verify_many(logn, pk, flat, sig, msg_off=off, debug=True, threads=8)
+        acc, gdbg = c.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
+        _compare_debug(logn, flags, odbg, acc, gdbg)
+        # fixed-length messages, pinned inputs and output
+        pk2, msg2, sig2, _ = corpus.generate(logn, count, seed=93 + logn, malformed_permille=200)
+        want = oracle.verify_many(logn, pk2, msg2, sig2, threads=8)[0]
+        bufs = [capi.PinnedArray(a.shape) for a in (pk2, msg2, sig2)] + [capi.PinnedArray((count,))]
+        pinned.extend(bufs)
+        for b, a in zip(bufs, (pk2, msg2, sig2)):
+            b.array[...] = a
+        out = c.verify_many(logn, bufs[0].array, bufs[1].array, bufs[2].array, accept_out=bufs[3].array)
+        assert out is bufs[3].array
+        np.testing.assert_array_equal(out, want & 1)
+        np.testing.assert_array_equal(c.verify_many(logn, pk2, msg2, sig2, norm_policy=1), (want >> 1) & 1)
+        # prepared keys: one per item, then a few shared ones named by index
+        prep = c.prepare_keys(logn, pk=pk2)
+        np.testing.assert_array_equal(c.verify_many_prepared(logn, prep, msg2, sig2), want & 1)
+        kidx = (np.arange(count) % 37).astype(np.uint32)
+        want2 = oracle.verify_many(logn, pk2[kidx], msg2, sig2, threads=8)[0]
+        np.testing.assert_array_equal(c.verify_many_prepared(logn, prep[:37], msg2, sig2, key_idx=kidx), want2 & 1)
+        # sub-batches large enough for the threaded staging of pageable memory (4 MiB pieces), and the runtime's own path
+        if logn == 9:
+            c.set_option(capi.OPT_HOST_CHUNK_ITEMS, 6000)
+            c.set_option(capi.OPT_CHUNK_ITEMS, 1 << 20)
+            pk3, msg3, sig3, _ = corpus.generate(logn, 16384, seed=97, malformed_permille=250, threads=8)
+            want3 = oracle.verify_many(logn, pk3, msg3, sig3, threads=8)[0] & 1
+            for threads in (6, 1, 0):
+                c.set_option(capi.OPT_HOST_THREADS, threads)
+                np.testing.assert_array_equal(c.verify_many(logn, pk3, msg3, sig3), want3, err_msg=f"host threads {threads}")
+    finally:
+        for b in pinned:
+            b.close()
+        c.close()
