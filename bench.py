@@ -173,9 +173,14 @@ def main():
         }
         result["kernels_ms_per_step"] = {k: v / args.steps for k, v in kern_ms.items()}
         per_gpu_rate = n_items * args.steps / elapsed
-        result["roofline_hbm"] = {"bound": "hbm", "achieved": per_gpu_rate * BYTES_512 / 1e9, "peak": PEAK_HBM_GBS,
-                                  "unit": "GB/s", "frac": per_gpu_rate * BYTES_512 / 1e9 / PEAK_HBM_GBS,
-                                  "algorithmic_bytes_per_item": BYTES_512}
+        # the same launch against the HBM roofline, in the contract's form: SURVEY.md 8(d)'s compulsory bytes per
+        # verify x the items one launch processes / that kernel's average launch time; traffic = measured HBM bytes
+        # of that launch (PMC, profiles/hbm_traffic.json). Far from the bound: the path is VALU-issue limited.
+        hbm_achieved = BYTES_512 * items_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        result["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": hbm_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": hbm_achieved / PEAK_HBM_GBS, "traffic": traffic,
+                                  "algorithmic_bytes_per_item": BYTES_512,
+                                  "whole_path_GBps": per_gpu_rate * BYTES_512 / 1e9}
         result["whole_path_valu_frac"] = per_gpu_rate * sum(OPS_512.values()) / 1e12 / PEAK_VALU_TIOPS
         result["retried_items"] = prof["retried_items"]
 

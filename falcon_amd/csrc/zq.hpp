@@ -26,7 +26,7 @@ constexpr uint32_t Q = 12289u;
 constexpr int32_t QI = 12289;
 constexpr int32_t RQ32 = 349496;  // round(2^32 / q): Shoup companion of w = 1
 
-struct Tw {
+struct alignas(8) Tw {  // 8-byte aligned: one ds_read_b64 (banked mod 64) instead of a ds_read2_b32 (banked mod 32, 2-way conflicts on the per-lane tables)
   int32_t w;   // twiddle, centred in (-q/2, q/2)
   int32_t wp;  // round(w * 2^32 / q)
 };
