@@ -19,7 +19,8 @@ EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile",
            "fa_verify_many_dev", "fa_verify_mixed", "fa_polymul_many", "fa_polymul_many_dev", "fa_pkey_len",
            "fa_sig_len", "fa_prepared_key_len", "fa_prepare_keys", "fa_prepare_keys_dev", "fa_verify_many_prepared",
            "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev", "fa_compute_public_keys",
-           "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister"]
+           "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister",
+           "fa_ntt_many", "fa_ntt_many_dev", "fa_decode_pkeys", "fa_decode_pkeys_dev", "fa_decode_sigs", "fa_decode_sigs_dev"]
 
 
 class FaDebug(ctypes.Structure):
@@ -73,6 +74,12 @@ def load_library():
     lib.fa_hash_to_point_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, vp]
     lib.fa_compute_public_keys.argtypes = [vp, i32, sz, vp, vp, vp]
     lib.fa_compute_public_keys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_ntt_many.argtypes = [vp, i32, sz, vp, vp, i32]
+    lib.fa_ntt_many_dev.argtypes = [vp, i32, sz, vp, vp, i32, vp]
+    lib.fa_decode_pkeys.argtypes = [vp, i32, sz, vp, vp, vp]
+    lib.fa_decode_pkeys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_decode_sigs.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+    lib.fa_decode_sigs_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
     lib.fa_host_alloc.argtypes = [sz]
     lib.fa_host_alloc.restype = vp
     lib.fa_host_free.argtypes = [vp]
@@ -288,6 +295,40 @@ class Context:
         c = np.zeros_like(a)
         _check(self.lib.fa_polymul_many(self.handle, logn, count, _ptr(a), _ptr(b), _ptr(c)), "fa_polymul_many")
         return c
+
+    def ntt_many(self, logn, a, inverse=False):
+        """ntt::ntt / ntt::intt (ntt.hpp:120-200) on every row of a (count, n) u16."""
+        a = np.ascontiguousarray(a, np.uint16)
+        count = a.shape[0]
+        if a.shape != (count, 1 << logn):
+            raise ValueError("a must be (count, n)")
+        out = np.zeros_like(a)
+        _check(self.lib.fa_ntt_many(self.handle, logn, count, _ptr(a), _ptr(out), 1 if inverse else 0), "fa_ntt_many")
+        return out
+
+    def decode_pkeys(self, logn, pk):
+        """decoding::decode_pkey (decoding.hpp:18-48): returns (h (count, n) u16, ok (count,) u8)."""
+        pk = np.ascontiguousarray(pk, np.uint8)
+        count = pk.shape[0]
+        if pk.shape != (count, self.lib.fa_pkey_len(logn)):
+            raise ValueError("pk shape does not match logn")
+        h = np.zeros((count, 1 << logn), np.uint16)
+        ok = np.zeros(count, np.uint8)
+        _check(self.lib.fa_decode_pkeys(self.handle, logn, count, _ptr(pk), _ptr(h), _ptr(ok)), "fa_decode_pkeys")
+        return h, ok
+
+    def decode_sigs(self, logn, sig, salt=None, s2=None):
+        """decoding::decode_sig (decoding.hpp:369-391): returns (salt (count, 40) u8, s2 (count, n) i16, ok). salt / s2
+        may be passed in to observe which rows the call leaves untouched (as the reference does on failure)."""
+        sig = np.ascontiguousarray(sig, np.uint8)
+        count = sig.shape[0]
+        if sig.shape != (count, self.lib.fa_sig_len(logn)):
+            raise ValueError("sig shape does not match logn")
+        salt = np.zeros((count, 40), np.uint8) if salt is None else salt
+        s2 = np.zeros((count, 1 << logn), np.int16) if s2 is None else s2
+        ok = np.zeros(count, np.uint8)
+        _check(self.lib.fa_decode_sigs(self.handle, logn, count, _ptr(sig), _ptr(salt), _ptr(s2), _ptr(ok)), "fa_decode_sigs")
+        return salt, s2, ok
 
     # ---- device-resident entry points (raw device pointers as ints) ----
     def verify_many_dev(self, logn, count, pk_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr, accept_ptr,

@@ -257,6 +257,43 @@ int timed(fa_ctx* ctx, hipStream_t s, int kind, F&& launch)
 
 bool aligned4(const void* p) { return ((uintptr_t)p & 3u) == 0; }
 
+// The signature decoders over `slots` consecutive rows of `sig`, into the context's workspace (s2 tiled,
+// sqn, st2): the fast decoder, then the generic one on the items it queued (those that met the k >= 8 rule).
+// The fix-up pass is one lane per queued item, a few hundred latency-bound waves at most; with `fork` it runs
+// on the context's second stream and the caller joins (hipStreamWaitEvent(s, ctx->ev_join)) before reading.
+template <int LOGN>
+int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig, bool fork)
+{
+  int rc;
+  if ((rc = ctx->s2.reserve(s2_tile_elems<LOGN>(slots) * 2))) return rc;
+  if ((rc = ctx->sqn.reserve((size_t)slots * 4))) return rc;
+  if ((rc = ctx->st2.reserve((size_t)slots))) return rc;
+  if ((rc = ctx->slow_count.reserve(4))) return rc;
+  if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
+  uint16_t* d_s2 = (uint16_t*)ctx->s2.p;
+  uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
+  uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
+  uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
+  uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
+  rc = timed(ctx, s, 0, [&] {
+    hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
+                       d_st2, d_cnt, d_list);
+  });
+  if (rc) return rc;
+  hipStream_t ds = fork ? ctx->aux : s;
+  if (fork) {
+    HIP_TRY(hipEventRecord(ctx->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(ds, ctx->ev_fork, 0));
+  }
+  rc = timed(ctx, ds, 0, [&] {
+    hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, ds, sig,
+                       (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2);
+  });
+  if (!rc && fork) rc = (int)hipEventRecord(ctx->ev_join, ds);
+  return rc;
+}
+
 // One pass of the three kernels over `slots` items. idx == nullptr: slot s is item s of the arrays
 // given (already offset to the chunk); else item idx[s] of the whole arrays.
 template <int LOGN>
@@ -283,29 +320,8 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
       hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
                          slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2);
     });
-  } else {  // fast decoder, then the generic one on the items it queued (those that met the k >= 8 rule)
-    if ((rc = ctx->slow_count.reserve(4))) return rc;
-    if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
-    uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
-    uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
-    rc = timed(ctx, s, 0, [&] {
-      hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
-                         d_st2, d_cnt, d_list);
-    });
-    if (rc) return rc;
-    // The fix-up pass is one lane per queued item: a few hundred latency-bound waves at most. It runs on
-    // the context's second stream beside the (VALU-bound) hash kernel and joins before the verify kernel.
-    hipStream_t ds = ctx->overlap ? ctx->aux : s;
-    if (ctx->overlap) {
-      HIP_TRY(hipEventRecord(ctx->ev_fork, s));
-      HIP_TRY(hipStreamWaitEvent(ds, ctx->ev_fork, 0));
-    }
-    rc = timed(ctx, ds, 0, [&] {
-      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, ds, sig,
-                         (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2);
-    });
-    if (!rc && ctx->overlap) rc = (int)hipEventRecord(ctx->ev_join, ds);
+  } else {
+    rc = decode_stage<LOGN>(ctx, s, slots, sig, ctx->overlap);
   }
   if (rc) return rc;
   rc = timed(ctx, s, 1, [&] {
@@ -512,6 +528,23 @@ int polymul_dev(fa_ctx* ctx, size_t count, const uint16_t* a, const uint16_t* b,
                          ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
     });
     if (rc) return rc;
+  }
+  return 0;
+}
+
+// decode_sig for a batch: the decoders chunk by chunk, then the untiling kernel.
+template <int LOGN>
+int decode_sigs_dev(fa_ctx* ctx, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok, hipStream_t s)
+{
+  constexpr size_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
+    const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
+    int rc = decode_stage<LOGN>(ctx, s, slots, sig + c0 * SIGLEN, false);
+    if (rc) return rc;
+    const uint32_t grid = std::min<uint32_t>((slots + 3) / 4, (uint32_t)ctx->num_cu * 16u);
+    hipLaunchKernelGGL(untile_sig_kernel<LOGN>, dim3(grid), dim3(256), 0, s, sig + c0 * SIGLEN, (const uint16_t*)ctx->s2.p,
+                       (const uint8_t*)ctx->st2.p, slots, salt + c0 * 40, s2 + (c0 << LOGN), ok + c0);
+    HIP_TRY(hipGetLastError());
   }
   return 0;
 }
@@ -1066,6 +1099,137 @@ int fa_compute_public_keys(fa_ctx* ctx, int logn, size_t count, const int32_t* f
                                   (uint16_t*)ctx->h_c.p, s);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h, ctx->h_c.p, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int fa_ntt_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, uint16_t* out, int inverse, void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!a || !out || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (((uintptr_t)a & 1u) || ((uintptr_t)out & 1u)) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  const int T = logn - 9;
+  const uint32_t n = (uint32_t)count;
+  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+#define FA_LAUNCH_NTT(LN, INV)                                                                                          \
+  hipLaunchKernelGGL((ntt_kernel<LN, INV>), dim3(grid), dim3(VERIFY_WG), 0, s, a, out, n, ctx->d_tw[T], ctx->d_itw[T],  \
+                     ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
+  if (logn == 9) {
+    if (inverse) FA_LAUNCH_NTT(9, true); else FA_LAUNCH_NTT(9, false);
+  } else {
+    if (inverse) FA_LAUNCH_NTT(10, true); else FA_LAUNCH_NTT(10, false);
+  }
+#undef FA_LAUNCH_NTT
+  return (int)hipGetLastError();
+}
+
+int fa_ntt_many(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, uint16_t* out, int inverse)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!a || !out) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t bytes = (count << logn) * 2;
+  int rc;
+  if ((rc = ctx->h_a.reserve(bytes))) return rc;
+  if ((rc = ctx->h_c.reserve(bytes))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_a.p, a, bytes, hipMemcpyHostToDevice, s));
+  rc = fa_ntt_many_dev(ctx, logn, count, (const uint16_t*)ctx->h_a.p, (uint16_t*)ctx->h_c.p, inverse, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, ctx->h_c.p, bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, uint16_t* h, uint8_t* ok, void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!pk || !h || !ok || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if ((uintptr_t)h & 1u) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n = (uint32_t)count;
+  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  if (logn == 9)
+    hipLaunchKernelGGL(decode_pkeys_kernel<9>, dim3(grid), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
+  else
+    hipLaunchKernelGGL(decode_pkeys_kernel<10>, dim3(grid), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
+  return (int)hipGetLastError();
+}
+
+int fa_decode_pkeys(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, uint16_t* h, uint8_t* ok)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!pk || !h || !ok) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t in_bytes = count * fa_pkey_len(logn), out_bytes = (count << logn) * 2;
+  int rc;
+  if ((rc = ctx->h_pk.reserve(in_bytes + 8))) return rc;
+  if ((rc = ctx->h_c.reserve(out_bytes))) return rc;
+  if ((rc = ctx->h_off.reserve(count))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, pk, in_bytes, hipMemcpyHostToDevice, s));
+  rc = fa_decode_pkeys_dev(ctx, logn, count, (const uint8_t*)ctx->h_pk.p, (uint16_t*)ctx->h_c.p, (uint8_t*)ctx->h_off.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h, ctx->h_c.p, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(ok, ctx->h_off.p, count, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int fa_decode_sigs_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok,
+                       void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!sig || !salt || !s2 || !ok || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (!aligned4(sig) || ((uintptr_t)s2 & 1u)) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  return logn == 9 ? decode_sigs_dev<9>(ctx, count, sig, salt, s2, ok, (hipStream_t)stream)
+                   : decode_sigs_dev<10>(ctx, count, sig, salt, s2, ok, (hipStream_t)stream);
+}
+
+int fa_decode_sigs(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!sig || !salt || !s2 || !ok) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t in_bytes = count * fa_sig_len(logn), s2_bytes = (count << logn) * 2;
+  int rc;
+  if ((rc = ctx->h_sig.reserve(in_bytes + 16))) return rc;
+  if ((rc = ctx->h_c.reserve(s2_bytes))) return rc;
+  if ((rc = ctx->h_msg.reserve(count * 40))) return rc;
+  if ((rc = ctx->h_off.reserve(count))) return rc;
+  hipStream_t s = ctx->stream;
+  // the caller's salt / s2 rows come along, so that rows the reference leaves untouched keep their contents
+  HIP_TRY(hipMemcpyAsync(ctx->h_sig.p, sig, in_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_c.p, s2, s2_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_msg.p, salt, count * 40, hipMemcpyHostToDevice, s));
+  rc = fa_decode_sigs_dev(ctx, logn, count, (const uint8_t*)ctx->h_sig.p, (uint8_t*)ctx->h_msg.p, (int16_t*)ctx->h_c.p,
+                          (uint8_t*)ctx->h_off.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s2, ctx->h_c.p, s2_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(salt, ctx->h_msg.p, count * 40, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(ok, ctx->h_off.p, count, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }

@@ -395,4 +395,31 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   sqn[slot] = norm;
 }
 
+// ---- decoding::decode_sig<N> (decoding.hpp:369-391) as a batched operator: the last step ----
+// The decoders above leave s2 lifted to [0, q) in the tiled workspace; this kernel (one wave per item) turns a
+// chunk of it into what the reference hands back: salt = bytes 1..40 and s2 as signed coefficients, natural
+// order. As in the reference, outputs are written only as far as it writes them: a wrong header leaves salt and
+// s2 alone (decoding.hpp:380-382), a body that does not decode zeroes s2 and leaves salt alone (:359, :385-387).
+template <int LOGN>
+__global__ __launch_bounds__(256) void untile_sig_kernel(const uint8_t* __restrict__ sig, const uint16_t* __restrict__ s2t,
+                                                         const uint8_t* __restrict__ st, uint32_t count,
+                                                         uint8_t* __restrict__ salt, int16_t* __restrict__ s2,
+                                                         uint8_t* __restrict__ ok)
+{
+  constexpr uint32_t N = 1u << LOGN, SIGLEN = LOGN == 9 ? 666 : 1280;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6); slot < count; slot += gridDim.x * 4u) {
+    const uint32_t status = st[slot];
+    if (lane == 0) ok[slot] = status == ST_OK ? 1 : 0;
+    if (status == ST_BAD_SIG_HEADER) continue;
+    const uint16_t* row = s2t + s2_tile_offset<LOGN>(slot, 0u);
+    for (uint32_t m = 0; m < N / 64u; m++) {  // i = 64 m + lane
+      const uint32_t v = row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];
+      const int32_t c = v > Q / 2u ? (int32_t)v - QI : (int32_t)v;
+      s2[(size_t)slot * N + 64u * m + lane] = status == ST_OK ? (int16_t)c : (int16_t)0;
+    }
+    if (status == ST_OK && lane < 40u) salt[(size_t)slot * 40u + lane] = sig[(size_t)slot * SIGLEN + 1u + lane];
+  }
+}
+
 }  // namespace fa

@@ -699,6 +699,74 @@ __global__ __launch_bounds__(VERIFY_WG) void pubkey_kernel(const int32_t* __rest
   }
 }
 
+// ---- ntt::ntt<LOG2N> / ntt::intt<LOG2N> (ntt.hpp:120-150, 161-200) as batched operators, out of place ----
+// One wave per polynomial. Forward: natural order in, bit-reversed order out -- position k of the output row is
+// position k of the reference's array after its in-place transform (the stages here act on the same index
+// bits with the same twiddle indices, only distributed over lanes), canonical residues. Inverse: the converse,
+// including the 1/N scaling (ntt.hpp:193-199). Inputs may be any u16; they are taken mod q as the ff_t
+// constructor does (ff.hpp:69-76).
+template <int LOGN, bool INVERSE>
+__global__ __launch_bounds__(VERIFY_WG) void ntt_kernel(const uint16_t* __restrict__ a, uint16_t* __restrict__ out, uint32_t count,
+                                                        const Tw* __restrict__ tw, const Tw* __restrict__ itw,
+                                                        const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                        const NttConsts nc)
+{
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, R = G::R;
+  __shared__ TwLds<LOGN> s_tw;
+  __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
+  for (uint32_t p = blockIdx.x * VERIFY_WAVES + wave; p < count; p += gridDim.x * VERIFY_WAVES) {
+    int32_t x[R];
+    if constexpr (!INVERSE) {
+#pragma unroll
+      for (int m = 0; m < R; m++) x[m] = (int32_t)a[(size_t)p * N + idxA<LOGN>(lane, m)];
+      ntt_forward<LOGN>(x, T, s_buf[wave], lane);
+#pragma unroll
+      for (int m = 0; m < R; m++) out[(size_t)p * N + idxC<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)reduce(x[m]), Q);
+    } else {
+#pragma unroll
+      for (int m = 0; m < R; m++) x[m] = reduce((int32_t)a[(size_t)p * N + idxC<LOGN>(lane, m)]);
+      ntt_inverse<LOGN>(x, T, s_buf[wave], lane, nc);
+#pragma unroll
+      for (int m = 0; m < R; m++) out[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)x[m], Q);
+    }
+    wave_lds_sync();
+  }
+}
+
+// ---- decoding::decode_pkey<N> (decoding.hpp:18-48) as a batched operator ----
+// One wave per key: h[key][N] = the raw 14-bit little-endian fields (values up to 16383 are stored as they are,
+// the reference does not range-check, decoding.hpp:34-45), ok[key] = 1; a wrong header byte gives a zero row
+// and ok[key] = 0 (decoding.hpp:29-32).
+template <int LOGN>
+__global__ __launch_bounds__(VERIFY_WG) void decode_pkeys_kernel(const uint8_t* __restrict__ pk, uint32_t nkeys,
+                                                                 uint16_t* __restrict__ h, uint8_t* __restrict__ ok)
+{
+  using G = Geo<LOGN>;
+  constexpr int N = G::N, R = G::R;
+  __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < nkeys; key += gridDim.x * VERIFY_WAVES) {
+    const uint8_t* pkrow = pk + (size_t)key * G::PKLEN;
+    const uint32_t pal = (uint32_t)((uintptr_t)pkrow & 3u);
+    const uint32_t* pbase = (const uint32_t*)(pkrow - pal);
+    const uint32_t last_dw = (pal + (uint32_t)G::PKLEN - 1u) >> 2;
+    uint32_t pkw[G::PKDW];
+#pragma unroll
+    for (int t = 0; t < G::PKDW; t++) pkw[t] = pbase[min(t * 64u + lane, last_dw)];
+    const bool good = ((__builtin_amdgcn_readfirstlane(pkw[0]) >> (8u * __builtin_amdgcn_readfirstlane(pal))) & 0xffu) == (uint32_t)LOGN;
+    int32_t y[R];
+    unpack_pkey<LOGN>(pkw, pal, s_pk[wave], lane, y);
+#pragma unroll
+    for (int m = 0; m < R; m++) h[(size_t)key * N + idxA<LOGN>(lane, m)] = good ? (uint16_t)y[m] : (uint16_t)0;
+    if (lane == 0) ok[key] = good ? 1 : 0;
+    wave_lds_sync();
+  }
+}
+
 // ---- batched negacyclic product c = a*b in Z_q[x]/(x^n+1) (BASELINE.json config 2) ----
 // Same transforms as the verify path: ntt, polynomial::mul, intt (tests/test_ntt.cpp:48-57).
 template <int LOGN>

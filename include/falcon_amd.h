@@ -152,6 +152,31 @@ int fa_polymul_many(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, cons
 int fa_polymul_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, const uint16_t* b, uint16_t* c,
                         void* stream);
 
+/* ---- ntt::ntt<LOG2N>(poly) / ntt::intt<LOG2N>(poly), ntt.hpp:120-150 and :161-200, batched, out of place ----
+ * a, out: count*N uint16. inverse == 0: natural order in, bit-reversed order out -- out[i][k] is element k of
+ * the reference's array after ntt(); inverse != 0: the converse, with the 1/N scaling (ntt.hpp:193-199).
+ * Inputs may be any uint16 (taken mod q as the ff_t constructor does, ff.hpp:69-76); results are canonical.
+ * _dev: device pointers, asynchronous on `stream`. */
+int fa_ntt_many(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, uint16_t* out, int inverse);
+int fa_ntt_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, uint16_t* out, int inverse, void* stream);
+
+/* ---- decoding::decode_pkey<N>(pkey, h), decoding.hpp:18-48, batched ----
+ * pk: count*pklen bytes; h: count*N uint16 = the raw 14-bit little-endian fields (up to 16383: the reference does
+ * not range-check them); ok[i] = the reference's bool. A wrong header byte gives a zero row (decoding.hpp:29-32).
+ * _dev: device pointers, asynchronous on `stream`. */
+int fa_decode_pkeys(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, uint16_t* h, uint8_t* ok);
+int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, uint16_t* h, uint8_t* ok, void* stream);
+
+/* ---- decoding::decode_sig<N>(sig, salt, s2), decoding.hpp:369-391 (decompress_sig :267-361), batched ----
+ * sig: count*siglen bytes; salt: count*40 bytes; s2: count*N int16 (the reference's int32_t values, all within
+ * [-1023, 1023]); ok[i] = the reference's bool. Outputs are written exactly as far as the reference writes them:
+ * a wrong header leaves salt[i] and s2[i] untouched (:380-382), a body that does not decode zeroes s2[i] and
+ * leaves salt[i] untouched (:359, :385-387). _dev: device pointers (sig 4-byte aligned), asynchronous on
+ * `stream`. */
+int fa_decode_sigs(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok);
+int fa_decode_sigs_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok,
+                       void* stream);
+
 /* Pinned host memory for the host-buffer entry points (no reference counterpart: the reference never
  * leaves the CPU). fa_host_alloc returns NULL on failure; fa_host_register pins an existing range
  * (page-granular, costly: worth it only for buffers that are reused). */

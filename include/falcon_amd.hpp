@@ -10,6 +10,9 @@
 //                                                      verification.hpp:20-26   verify with the key kept decoded
 //   falcon::hash_to_point_many<N>(count, salts, ...)   hashing.hpp:16-50
 //   falcon::compute_public_keys<N>(count, f, g, h)     keygen.hpp:67-90
+//   falcon::ntt_many<N> / intt_many<N>(count, a, out)  ntt.hpp:120-150 / 161-200
+//   falcon::decode_pkeys<N>(count, pkeys, h, ok)       decoding.hpp:18-48
+//   falcon::decode_sigs<N>(count, sigs, salts, s2, ok) decoding.hpp:369-391
 //
 // Both run on the GPU through the C ABI of falcon_amd.h (libfalcon_amd.so); there is no CPU path
 // in this header. Conventions are the reference's: the caller owns every
@@ -235,6 +238,38 @@ inline void compute_public_keys(size_t count, const int32_t* f, const int32_t* g
 {
   const int rc = fa_compute_public_keys(detail::context(device), detail::logn<N>(), count, f, g, h);
   if (rc) throw device_error("fa_compute_public_keys", rc);
+}
+
+// ntt::ntt<log2 N>(poly) / ntt::intt<log2 N>(poly) (ntt.hpp:120-150, 161-200) on `count` polynomials, out of place:
+// natural order in and bit-reversed order out for ntt_many, the converse (with the 1/N scaling) for intt_many.
+template<size_t N>
+inline void ntt_many(size_t count, const uint16_t* a, uint16_t* out, int device = 0)
+{
+  const int rc = fa_ntt_many(detail::context(device), detail::logn<N>(), count, a, out, 0);
+  if (rc) throw device_error("fa_ntt_many", rc);
+}
+template<size_t N>
+inline void intt_many(size_t count, const uint16_t* a, uint16_t* out, int device = 0)
+{
+  const int rc = fa_ntt_many(detail::context(device), detail::logn<N>(), count, a, out, 1);
+  if (rc) throw device_error("fa_ntt_many", rc);
+}
+
+// decoding::decode_pkey<N>(pkey, h) (decoding.hpp:18-48) for `count` keys; ok[i] is the reference's bool.
+template<size_t N>
+inline void decode_pkeys(size_t count, const uint8_t* pkeys, uint16_t* h, uint8_t* ok, int device = 0)
+{
+  const int rc = fa_decode_pkeys(detail::context(device), detail::logn<N>(), count, pkeys, h, ok);
+  if (rc) throw device_error("fa_decode_pkeys", rc);
+}
+
+// decoding::decode_sig<N>(sig, salt, s2) (decoding.hpp:369-391) for `count` signatures; s2 as int16 (the reference's
+// int32 values lie in [-1023, 1023]); rows of failing items are written exactly as far as the reference writes them.
+template<size_t N>
+inline void decode_sigs(size_t count, const uint8_t* sigs, uint8_t* salts, int16_t* s2, uint8_t* ok, int device = 0)
+{
+  const int rc = fa_decode_sigs(detail::context(device), detail::logn<N>(), count, sigs, salts, s2, ok);
+  if (rc) throw device_error("fa_decode_sigs", rc);
 }
 
 // falcon.hpp:230-249. `sig` is non-const there too (never written).

@@ -101,6 +101,14 @@ class Oracle:
         ok = self.lib.fo_decompress_sig(logn, _p(sig), _p(s, ctypes.c_int32))
         return bool(ok), s
 
+    def decode_sig(self, logn, sig, salt=None, s2=None):
+        """decoding::decode_sig; salt / s2 may be passed in to observe what a failing call leaves untouched."""
+        sig = np.ascontiguousarray(sig, np.uint8)
+        salt = np.zeros(40, np.uint8) if salt is None else salt
+        s2 = np.zeros(1 << logn, np.int32) if s2 is None else s2
+        ok = self.lib.fo_decode_sig(logn, _p(sig), _p(salt), _p(s2, ctypes.c_int32))
+        return ok == 1, salt, s2  # 0: wrong header, -1: body does not decode
+
     def ntt(self, a, logn):
         a = np.array(a, np.uint16)
         self.lib.fo_ntt(_p(a, ctypes.c_uint16), logn)

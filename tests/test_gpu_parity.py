@@ -311,3 +311,62 @@ def test_host_pipeline_sub_batches(oracle, corpus, logn):
         for b in pinned:
             b.close()
         c.close()
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_ntt_many(ctx, oracle, logn):
+    """ntt::ntt / ntt::intt as batched operators (ntt.hpp:120-200): element for element the reference's arrays
+    (bit-reversed output order included), and the round trip of tests/test_ntt.cpp:48-57."""
+    n = 1 << logn
+    rng = np.random.default_rng(100 + logn)
+    a = rng.integers(0, 12289, (70, n)).astype(np.uint16)
+    a[0] = np.arange(n) % 12289
+    a[1] = 12288
+    a[2] = 0
+    a[3] = rng.integers(12289, 65536, n)  # non-canonical input: taken mod q, as the ff_t constructor does
+    fwd = ctx.ntt_many(logn, a)
+    want = np.stack([oracle.ntt(row % 12289, logn) for row in a])
+    np.testing.assert_array_equal(fwd, want)
+    inv = ctx.ntt_many(logn, fwd, inverse=True)
+    np.testing.assert_array_equal(inv, a % 12289)
+    b = rng.integers(0, 65536, (5, n)).astype(np.uint16)
+    np.testing.assert_array_equal(ctx.ntt_many(logn, b, inverse=True), np.stack([oracle.intt(row % 12289, logn) for row in b]))
+    assert ctx.ntt_many(logn, a[:0]).shape == (0, n)
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_decode_pkeys_and_sigs(ctx, oracle, corpus, logn):
+    """decoding::decode_pkey and decoding::decode_sig as batched operators, every malformed class included: the
+    same h / salt / s2 / bool as the oracle, and rows of failing items written exactly as far as the reference
+    writes them (decoding.hpp:29-32, 359, 380-387)."""
+    n = 1 << logn
+    count = 700
+    pk, _, sig, kinds = corpus.generate(logn, count, seed=55 + logn, malformed_permille=500)
+    h, ok = ctx.decode_pkeys(logn, pk)
+    for i in range(count):
+        o_ok, o_h = oracle.decode_pkey(logn, pk[i])
+        assert bool(ok[i]) == o_ok
+        np.testing.assert_array_equal(h[i], o_h)
+    assert (ok == 0).any() and (h >= 12289).any()  # wrong headers and coefficients >= q are both in the corpus
+    salt0 = np.full((count, 40), 0xA5, np.uint8)
+    s20 = np.full((count, n), 0x5A5A, np.int16)
+    salt, s2, sok = ctx.decode_sigs(logn, sig, salt=salt0.copy(), s2=s20.copy())
+    seen = set()
+    for i in range(count):
+        o_ok, o_salt, o_s2 = oracle.decode_sig(logn, sig[i], salt=salt0[i].copy(), s2=s20[i].astype(np.int32))
+        assert bool(sok[i]) == o_ok, (i, support.KINDS[kinds[i]])
+        np.testing.assert_array_equal(salt[i], o_salt)
+        np.testing.assert_array_equal(s2[i].astype(np.int32), o_s2)
+        seen.add((o_ok, bool((o_s2 == 0x5A5A).all())))
+    assert seen == {(True, False), (False, True), (False, False)}  # decoded, wrong header (untouched), bad body (zeroed)
+    # chunked: several passes of the decoders
+    from falcon_amd import capi
+    c = capi.Context(0)
+    try:
+        c.set_option(capi.OPT_CHUNK_ITEMS, 128)
+        salt_c, s2_c, ok_c = c.decode_sigs(logn, sig, salt=salt0.copy(), s2=s20.copy())
+        np.testing.assert_array_equal(salt_c, salt)
+        np.testing.assert_array_equal(s2_c, s2)
+        np.testing.assert_array_equal(ok_c, sok)
+    finally:
+        c.close()
