@@ -27,10 +27,15 @@ def sig_len(logn):
 
 
 def _build(subdir, lib):
+    """Load <subdir>/<lib>, running make first when the source is newer. Serialised by a file lock: the ranks of a
+    multi-process bench all come through here at once."""
+    import fcntl
     path = os.path.join(ROOT, subdir, lib)
     src = os.path.join(ROOT, subdir, lib[3:-3] + ".c")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, subdir)], stdout=subprocess.DEVNULL)
+    with open(os.path.join(ROOT, subdir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, subdir)], stdout=subprocess.DEVNULL)
     return ctypes.CDLL(path)
 
 
