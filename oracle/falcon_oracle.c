@@ -14,11 +14,17 @@
  *   - SHAKE256 lives in the third-party submodule itzmeanjan/sha3 (.gitmodules:1-3, pinned
  *     commit unknown, directory empty in /root/reference), so it is restated from FIPS 202
  *     and pinned against Python's hashlib.shake_256 in tests/test_oracle.py;
- *   - Falcon-1024: the reference holds NO known-answer vector for N=1024 ("parity unpinned"
- *     beyond the shared code and the algebraic checks in tests/test_oracle.py).
- *
- * The reference cannot be compiled here without writing a stand-in for the absent sha3
- * header, so there is no oracle/_ref build.
+ *   - the reference ITSELF, for everything of the path that compiles without the sha3 submodule:
+ *     oracle/_ref/libfalcon_ref.so (oracle/ref_harness.cpp over the reference's decoding.hpp,
+ *     encoding.hpp, ntt.hpp, ff.hpp, polynomial.hpp, included where they lie). tests/test_ref_parity.py
+ *     holds this file to it for N = 512 and 1024: decode_pkey, decode_sig / decompress_sig (every
+ *     malformed class, differential fuzz, what a failing call leaves behind), ntt / intt element for
+ *     element, the field operations, and s1 / the norm through verification.hpp:36-79 carried out with
+ *     the reference's functions;
+ *   - what stays pinned only indirectly: hashing.hpp / verification.hpp cannot be built (they include
+ *     the absent shake256.hpp and a stand-in header is not allowed), so hash_to_point is pinned by
+ *     hashlib (FIPS 202) + the README triple, and the reference holds no Falcon-1024 known-answer
+ *     vector for it ("parity unpinned" for hash_to_point<1024> beyond hashlib and the shared code).
  *
  * Norm semantics: verification.hpp:70-79 accumulates in int32_t, which overflows (UB) for
  * most invalid signatures. The oracle reports the exact 64-bit norm AND the value wrapped to

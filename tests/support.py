@@ -189,8 +189,93 @@ class Corpus:
         return pk, msg[:, :mlen], sig, kinds
 
 
+class Reference:
+    """oracle/_ref/libfalcon_ref.so: the reference's own headers behind C entry points (oracle/ref_harness.cpp),
+    built in the container where /root/reference exists. Used only to pin the oracle and the HIP path."""
+
+    PATH = os.path.join(ROOT, "oracle", "_ref", "libfalcon_ref.so")
+
+    def __init__(self):
+        self.lib = lib = ctypes.CDLL(self.PATH)
+        u16p, i32p, i16p = (ctypes.POINTER(t) for t in (ctypes.c_uint16, ctypes.c_int32, ctypes.c_int16))
+        lib.fr_decode_pkey.argtypes = [ctypes.c_uint, _u8p, u16p]
+        lib.fr_decompress_sig.argtypes = [ctypes.c_uint, _u8p, i32p]
+        lib.fr_decode_sig.argtypes = [ctypes.c_uint, _u8p, _u8p, i32p]
+        lib.fr_encode_pkey.argtypes = [ctypes.c_uint, u16p, _u8p]
+        lib.fr_compress_sig.argtypes = [ctypes.c_uint, i32p, _u8p]
+        lib.fr_ntt.argtypes = [ctypes.c_uint, u16p]
+        lib.fr_intt.argtypes = [ctypes.c_uint, u16p]
+        lib.fr_ff_op.argtypes = [ctypes.c_int, ctypes.c_size_t, u16p, u16p, u16p]
+        lib.fr_verify_after_hash.argtypes = [ctypes.c_uint, u16p, u16p, i32p, i16p]
+        lib.fr_verify_after_hash.restype = ctypes.c_uint64
+
+    def decode_pkey(self, logn, pk):
+        pk = np.ascontiguousarray(pk, np.uint8)
+        h = np.full(1 << logn, 0xBEEF, np.uint16)
+        ok = self.lib.fr_decode_pkey(logn, _p(pk), _p(h, ctypes.c_uint16))
+        return bool(ok), h
+
+    def decompress_sig(self, logn, sig):
+        sig = np.ascontiguousarray(sig, np.uint8)
+        s = np.full(1 << logn, 77, np.int32)
+        ok = self.lib.fr_decompress_sig(logn, _p(sig), _p(s, ctypes.c_int32))
+        return bool(ok), s
+
+    def decode_sig(self, logn, sig, salt=None, s2=None):
+        sig = np.ascontiguousarray(sig, np.uint8)
+        salt = np.zeros(40, np.uint8) if salt is None else salt
+        s2 = np.zeros(1 << logn, np.int32) if s2 is None else s2
+        ok = self.lib.fr_decode_sig(logn, _p(sig), _p(salt), _p(s2, ctypes.c_int32))
+        return bool(ok), salt, s2
+
+    def encode_pkey(self, logn, h):
+        h = np.ascontiguousarray(h, np.uint16)
+        pk = np.zeros(pk_len(logn), np.uint8)
+        self.lib.fr_encode_pkey(logn, _p(h, ctypes.c_uint16), _p(pk))
+        return pk
+
+    def compress_sig(self, logn, s2):
+        """Returns (ok, sig) with bytes 0..40 zero: the reference's compress_sig leaves header and salt alone."""
+        s2 = np.ascontiguousarray(s2, np.int32)
+        sig = np.zeros(sig_len(logn), np.uint8)
+        ok = self.lib.fr_compress_sig(logn, _p(s2, ctypes.c_int32), _p(sig))
+        return bool(ok), sig
+
+    def ntt(self, a, logn, inverse=False):
+        a = np.array(a, np.uint16)
+        (self.lib.fr_intt if inverse else self.lib.fr_ntt)(logn, _p(a, ctypes.c_uint16))
+        return a
+
+    def ff_op(self, op, a, b):
+        a = np.ascontiguousarray(a, np.uint16)
+        b = np.ascontiguousarray(b, np.uint16)
+        out = np.zeros_like(a)
+        self.lib.fr_ff_op(op, a.size, _p(a, ctypes.c_uint16), _p(b, ctypes.c_uint16), _p(out, ctypes.c_uint16))
+        return out
+
+    def verify_after_hash(self, logn, h, c, s2):
+        """verification.hpp:36-79 with the reference's functions. Returns (s1 centred int16, exact norm)."""
+        h = np.ascontiguousarray(h, np.uint16)
+        c = np.ascontiguousarray(c, np.uint16)
+        s2 = np.ascontiguousarray(s2, np.int32)
+        s1 = np.zeros(1 << logn, np.int16)
+        norm = self.lib.fr_verify_after_hash(logn, _p(h, ctypes.c_uint16), _p(c, ctypes.c_uint16), _p(s2, ctypes.c_int32),
+                                             _p(s1, ctypes.c_int16))
+        return s1, int(norm)
+
+
 _oracle = None
 _corpus = None
+_reference = None
+
+
+def reference():
+    """The reference-backed library, or None where it has not been built (no /root/reference at build time)."""
+    global _reference
+    if _reference is None and os.path.exists(Reference.PATH):
+        _reference = Reference()
+    return _reference
+
 
 
 def oracle():
