@@ -370,3 +370,28 @@ def test_decode_pkeys_and_sigs(ctx, oracle, corpus, logn):
         np.testing.assert_array_equal(ok_c, sok)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_reference_output_fixture(ctx, logn):
+    """tests/golden/ref_outputs.npz: what the reference's own code returns for the inputs of corpus_small.npz
+    (tests/golden/make_ref_golden.py). The HIP operators and the verify path's debug outputs must equal them."""
+    g = np.load(os.path.join(GOLDEN, "corpus_small.npz"), allow_pickle=False)
+    r = np.load(os.path.join(GOLDEN, "ref_outputs.npz"), allow_pickle=False)
+    n = 1 << logn
+    pk, sig = g[f"pk{logn}"], g[f"sig{logn}"]
+    h, ok = ctx.decode_pkeys(logn, pk)
+    np.testing.assert_array_equal(ok, r[f"pk_ok{logn}"])
+    np.testing.assert_array_equal(h, r[f"h{logn}"])
+    salt, s2, sok = ctx.decode_sigs(logn, sig)  # zeroed outputs, as the fixture's calls
+    np.testing.assert_array_equal(sok, r[f"sig_ok{logn}"])
+    np.testing.assert_array_equal(salt, r[f"salt{logn}"])
+    np.testing.assert_array_equal(s2, r[f"s2_{logn}"])
+    acc, dbg = ctx.verify_many(logn, pk, g[f"msg{logn}"], sig, msg_off=g[f"off{logn}"], debug=True)
+    both = (r[f"pk_ok{logn}"] & r[f"sig_ok{logn}"]).astype(bool)
+    np.testing.assert_array_equal(dbg["norm_exact"][both], r[f"norm{logn}"][both])
+    np.testing.assert_array_equal(dbg["s1"][both], r[f"s1_{logn}"][both])
+    np.testing.assert_array_equal(acc[both], (r[f"norm{logn}"][both] <= support.BETA2[logn]).astype(np.uint8))
+    assert not acc[~both].any()
+    np.testing.assert_array_equal(ctx.ntt_many(logn, r[f"poly{logn}"]), r[f"ntt{logn}"])
+    np.testing.assert_array_equal(ctx.ntt_many(logn, r[f"poly{logn}"], inverse=True), r[f"intt{logn}"])
