@@ -113,6 +113,24 @@ __device__ __forceinline__ Tw twiddle(const Tw* __restrict__ tw, uint32_t lanepa
   return tw[twc_offset<LOGN>(lb) + (m >> (lb + 1))];
 }
 
+// Instruction order inside a stage. Measured on the box (tools/valu_mix.hip, profiles/valu_mix_r01.json): a
+// full-rate instruction (add, sub) issues in 2 cycles only next to others of its kind; alternating with half-rate
+// instructions (the multiplies) it takes a 4-cycle slot like them. hipcc emits a stage butterfly after butterfly
+// (mul_hi, mul, mad, sub, add, mul_hi, ...), a dependent chain of five; grouped by kind (all mul_hi of the stage,
+// all mul, all mad, then all subs and adds) neighbours are independent and the adds form runs. In the kernels this
+// is worth 4 % for Falcon-1024 (8 butterflies per stage and lane, two waves per SIMD) and nothing measurable for
+// Falcon-512 (4 per stage, five waves per SIMD: the other waves already fill the slots). The fences keep hipcc's
+// scheduler from undoing the grouping: vector ALU instructions may not cross them, LDS, memory and scalar ones may.
+#ifndef FA_GROUPED
+#define FA_GROUPED 1
+#endif
+__device__ __forceinline__ void valu_fence()
+{
+#if FA_GROUPED
+  __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80);  // SALU, VMEM and DS instructions may be scheduled across
+#endif
+}
+
 // Cooley-Tukey stages on register bits LBTOP .. LBTOP-NST+1 of x[] (global bits BTOP ..).
 // Values are lazy signed residues (zq.hpp): a stage widens the bound by q, nothing is reduced.
 template <int LOGN, int NST, int BTOP, int LBTOP, int KIND>
@@ -122,14 +140,40 @@ __device__ __forceinline__ void ct_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
 #pragma unroll
   for (int s = 0; s < NST; s++) {
     const int b = BTOP - s, lb = LBTOP - s;
+    int32_t qh[R / 2], v[R / 2];
+    Tw t[R / 2];
+    valu_fence();
 #pragma unroll
-    for (int m = 0; m < R; m++) {
+    for (int m = 0, k = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
-      const Tw t = twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      const int32_t v = shoup(x[m | (1 << lb)], t.w, t.wp);  // [0, q]
-      x[m | (1 << lb)] = x[m] - v;
-      x[m] = x[m] + v;
+      t[k] = twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
+      qh[k] = __mulhi(x[m | (1 << lb)], t[k].wp);
+      k++;
     }
+    valu_fence();
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      v[k] = __mul24(x[m | (1 << lb)], t[k].w);
+      k++;
+    }
+    valu_fence();
+#pragma unroll
+    for (int k = 0; k < R / 2; k++) v[k] = mad_i24(qh[k], -QI, v[k]);  // shoup(x, w, wp), in [0, q]
+    valu_fence();
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      x[m | (1 << lb)] = x[m] - v[k];
+      k++;
+    }
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      x[m] = x[m] + v[k];
+      k++;
+    }
+    valu_fence();
   }
 }
 
@@ -146,15 +190,48 @@ __device__ __forceinline__ void gs_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
   for (int s = 0; s < NST; s++) {
     const int b = BBOT + s, lb = LBBOT + s;
     const bool last = LAST && s == NST - 1;
+    const bool red = !last && REDUCE && s == NST - 1;
+    int32_t d[R / 2], qh[R / 2], qu[R / 2];
+    Tw t[R / 2];
+    valu_fence();
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {  // differences and sums first: a run of full-rate instructions
+      if (m & (1 << lb)) continue;
+      d[k] = x[m] - x[m | (1 << lb)];
+      k++;
+    }
 #pragma unroll
     for (int m = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
-      const Tw t = last ? nc.inv_last : twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      const int32_t u = x[m] + x[m | (1 << lb)];
-      const int32_t d = x[m] - x[m | (1 << lb)];
-      x[m | (1 << lb)] = shoup(d, t.w, t.wp);
-      x[m] = last ? shoup(u, nc.ninv.w, nc.ninv.wp) : (REDUCE && s == NST - 1) ? reduce(u) : u;
+      x[m] = x[m] + x[m | (1 << lb)];
     }
+    valu_fence();
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      t[k] = last ? nc.inv_last : twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
+      qh[k] = __mulhi(d[k], t[k].wp);
+      if (last) qu[k] = __mulhi(x[m], nc.ninv.wp);
+      if (red) qu[k] = __mulhi(x[m], RQ32);
+      k++;
+    }
+    valu_fence();
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      d[k] = __mul24(d[k], t[k].w);
+      if (last) x[m] = __mul24(x[m], nc.ninv.w);
+      k++;
+    }
+    valu_fence();
+#pragma unroll
+    for (int m = 0, k = 0; m < R; m++) {
+      if (m & (1 << lb)) continue;
+      x[m | (1 << lb)] = mad_i24(qh[k], -QI, d[k]);       // shoup(d, w, wp)
+      if (last || red) x[m] = mad_i24(qu[k], -QI, x[m]);  // shoup(u, 1/N) resp. reduce(u)
+      k++;
+    }
+    valu_fence();
   }
 }
 
