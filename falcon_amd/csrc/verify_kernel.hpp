@@ -147,7 +147,7 @@ __device__ __forceinline__ void ct_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
     for (int m = 0, k = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
       t[k] = twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      qh[k] = __mulhi(x[m | (1 << lb)], t[k].wp);
+      qh[k] = mulhi_i32<KIND == TW_UNIFORM>(x[m | (1 << lb)], t[k].wp);
       k++;
     }
     valu_fence();
@@ -159,7 +159,7 @@ __device__ __forceinline__ void ct_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
     }
     valu_fence();
 #pragma unroll
-    for (int k = 0; k < R / 2; k++) v[k] = mad_i24(qh[k], -QI, v[k]);  // shoup(x, w, wp), in [0, q]
+    for (int k = 0; k < R / 2; k++) v[k] = msub_q(qh[k], v[k]);  // shoup(x, w, wp), in [0, q]
     valu_fence();
 #pragma unroll
     for (int m = 0, k = 0; m < R; m++) {
@@ -210,9 +210,9 @@ __device__ __forceinline__ void gs_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
     for (int m = 0, k = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
       t[k] = last ? nc.inv_last : twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      qh[k] = __mulhi(d[k], t[k].wp);
-      if (last) qu[k] = __mulhi(x[m], nc.ninv.wp);
-      if (red) qu[k] = __mulhi(x[m], RQ32);
+      qh[k] = mulhi_i32<LAST || KIND == TW_UNIFORM>(d[k], t[k].wp);
+      if (last) qu[k] = mulhi_i32<true>(x[m], nc.ninv.wp);
+      if (red) qu[k] = mulhi_i32<true>(x[m], RQ32);
       k++;
     }
     valu_fence();
@@ -227,8 +227,8 @@ __device__ __forceinline__ void gs_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
 #pragma unroll
     for (int m = 0, k = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
-      x[m | (1 << lb)] = mad_i24(qh[k], -QI, d[k]);       // shoup(d, w, wp)
-      if (last || red) x[m] = mad_i24(qu[k], -QI, x[m]);  // shoup(u, 1/N) resp. reduce(u)
+      x[m | (1 << lb)] = msub_q(qh[k], d[k]);       // shoup(d, w, wp)
+      if (last || red) x[m] = msub_q(qu[k], x[m]);  // shoup(u, 1/N) resp. reduce(u)
       k++;
     }
     valu_fence();

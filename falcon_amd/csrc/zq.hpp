@@ -36,11 +36,33 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 
 // a * b + c with a, b signed 24-bit: one v_mad_i32_i24 (the backend fuses mul24 + add).
 __device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
 
+// (a * b) >> 32, signed: one v_mul_hi_i32, named. __mulhi is a 64-bit product in LLVM IR; where b is loop-invariant
+// (the wave-uniform twiddles, 2^32/q) the sign extension of b is hoisted out of the loop and the product then comes
+// back as a five-instruction 64-bit multiply. UNIFORM_B: b lives in an SGPR.
+template <bool UNIFORM_B>
+__device__ __forceinline__ int32_t mulhi_i32(int32_t a, int32_t b)
+{
+  int32_t r;
+  if constexpr (UNIFORM_B)
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  else
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// qh * (-q) + p with |qh| < 2^23 (a quotient estimate): one v_mad_i32_i24, named -- left to itself hipcc
+// sign-extends qh from 24 bits first in places (two more instructions) or picks the 64-bit v_mad_u64_u32.
+__device__ __forceinline__ int32_t msub_q(int32_t qh, int32_t p)
+{
+  int32_t r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(qh), "s"(-QI), "v"(p));
+  return r;
+}
+
 // |x| < 2^19  ->  (x * w) mod q as a value in [0, q].
 __device__ __forceinline__ int32_t shoup(int32_t x, int32_t w, int32_t wp)
 {
-  const int32_t qh = __mulhi(x, wp);
-  return mad_i24(qh, -QI, __mul24(x, w));
+  return msub_q(mulhi_i32<false>(x, wp), __mul24(x, w));
 }
 
 // |x| < 2^22  ->  x mod q as a value in [0, q] (the companion of w = 1 is off by only 0.04, so the
@@ -48,10 +70,7 @@ __device__ __forceinline__ int32_t shoup(int32_t x, int32_t w, int32_t wp)
 // v_mad_u64_u32 here; the multiplier must be wave-uniform (SGPR operand).
 __device__ __forceinline__ int32_t reduce(int32_t x)
 {
-  const int32_t qh = __mulhi(x, RQ32);
-  int32_t r;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(qh), "s"(-QI), "v"(x));
-  return r;
+  return msub_q(mulhi_i32<true>(x, RQ32), x);
 }
 
 // Conditional subtract: X < 2*M  ->  X mod M (unsigned min trick, 2 instructions).
@@ -80,9 +99,7 @@ __device__ __forceinline__ int32_t mulmod(int32_t a, int32_t b)
 __device__ __forceinline__ int32_t mulmod_lazy(int32_t a, int32_t b)
 {
   const int32_t p = a * b;
-  int32_t r;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__mulhi(p, RQ32)), "s"(-QI), "v"(p));
-  return r;
+  return msub_q(mulhi_i32<true>(p, RQ32), p);
 }
 
 }  // namespace fa
