@@ -65,7 +65,7 @@ struct NttConsts {
   Tw itwA[16];  // inverse twiddles 0..R-1
 };
 
-enum { TW_UNIFORM = 0, TW_PHASE_B = 1, TW_PHASE_C = 2 };
+enum { TW_UNIFORM = 0, TW_PHASE_B = 1, TW_PHASE_C = 2, TW_UNIFORM_LDS = 3 };
 
 // element index held by (lane, reg m) in each phase
 template <int LOGN> __device__ __forceinline__ uint32_t idxA(uint32_t lane, int m) { return ((uint32_t)m << 6) | lane; }
@@ -103,12 +103,15 @@ __device__ __forceinline__ void wave_lds_sync()
 // Twiddle of the butterfly (m, m | 1<<lb) at global bit b. Reference index (ntt.hpp:133):
 //   (N >> (b+1)) + (i >> (b+1)),  i >> (b+1) = (lanepart << (LB-1-lb)) | (m >> (lb+1)).
 // KIND selects where it lives; `tw` is the kernel-argument array, the phase-B LDS table, or this
-// lane's row of the phase-C LDS table.
+// lane's row of the phase-C LDS table. TW_UNIFORM_LDS: lane-uniform like TW_UNIFORM but read (as a broadcast)
+// from the LDS table that holds the reference-order twiddles -- Falcon-1024's widest phase-A stage has 8 twiddle
+// pairs per direction, which as kernel arguments pushed the kernel past its SGPR budget (the spills went to VGPR
+// lanes: 80 v_writelane / v_readlane per item).
 template <int LOGN, int KIND>
 __device__ __forceinline__ Tw twiddle(const Tw* __restrict__ tw, uint32_t lanepart, int b, int lb, int m)
 {
   constexpr int LB = Geo<LOGN>::LB, N = Geo<LOGN>::N;
-  if constexpr (KIND == TW_UNIFORM) return tw[(N >> (b + 1)) + (m >> (lb + 1))];
+  if constexpr (KIND == TW_UNIFORM || KIND == TW_UNIFORM_LDS) return tw[(N >> (b + 1)) + (m >> (lb + 1))];
   if constexpr (KIND == TW_PHASE_B) return tw[(N >> (b + 1)) + (lanepart << (LB - 1 - lb)) + (m >> (lb + 1))];
   return tw[twc_offset<LOGN>(lb) + (m >> (lb + 1))];
 }
@@ -278,13 +281,26 @@ struct TwTabs {
   const Tw* iC;
 };
 
+// Phase A of the forward transform: the stages on the register-held index bits [6, logn), lane-uniform twiddles.
+template <int LOGN>
+__device__ __forceinline__ void phase_a_forward(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T)
+{
+  using G = Geo<LOGN>;
+  if constexpr (LOGN == 10) {
+    ct_stages<LOGN, G::LB - 1, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
+    ct_stages<LOGN, 1, 6, 0, TW_UNIFORM_LDS>(x, T.fB, 0u);
+  } else {
+    ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
+  }
+}
+
 // x: |x| < 2^16 in phase-A layout  ->  NTT in phase-C layout, |x| < 2^16 + logn*q
 template <int LOGN>
 __device__ __forceinline__ void ntt_forward(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
                                             uint32_t lane)
 {
   using G = Geo<LOGN>;
-  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
+  phase_a_forward<LOGN>(x, T);
   transpose<LOGN, 0>(x, buf, lane);
   ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB);
   transpose<LOGN, 1>(x, buf, lane);
@@ -299,9 +315,9 @@ __device__ __forceinline__ void ntt_forward2(int32_t (&x)[Geo<LOGN>::R], int32_t
                                              uint32_t* __restrict__ bufx, uint32_t* __restrict__ bufy, uint32_t lane)
 {
   using G = Geo<LOGN>;
-  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
+  phase_a_forward<LOGN>(x, T);
   transpose_out<LOGN, 0>(x, bufx, lane);
-  ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(y, T.fA, 0u);
+  phase_a_forward<LOGN>(y, T);
   transpose_out<LOGN, 0>(y, bufy, lane);
   wave_lds_sync();
   transpose_in<LOGN, 0>(x, bufx, lane);
@@ -332,7 +348,12 @@ __device__ __forceinline__ void ntt_inverse(int32_t (&x)[Geo<LOGN>::R], const Tw
   transpose<LOGN, 2>(x, buf, lane);
   gs_stages<LOGN, G::LB, G::PB, 0, false, true, TW_PHASE_B>(x, T.iB, lane >> G::PB, nc);
   transpose<LOGN, 3>(x, buf, lane);
-  gs_stages<LOGN, G::LB, 6, 0, true, false, TW_UNIFORM>(x, T.iA, 0u, nc);
+  if constexpr (LOGN == 10) {
+    gs_stages<LOGN, 1, 6, 0, false, false, TW_UNIFORM_LDS>(x, T.iB, 0u, nc);
+    gs_stages<LOGN, G::LB - 1, 7, 1, true, false, TW_UNIFORM>(x, T.iA, 0u, nc);
+  } else {
+    gs_stages<LOGN, G::LB, 6, 0, true, false, TW_UNIFORM>(x, T.iA, 0u, nc);
+  }
 }
 
 // Workgroup-shared twiddle tables in LDS and their one-time fill.
