@@ -552,11 +552,6 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];  // transposes; the key row is staged in it before the first one
   __shared__ uint16_t s_c[VERIFY_WAVES][N];
-  // Falcon-1024 runs two waves per SIMD (registers), where interleaving the two forward transforms pays
-  // (measured 4.9 -> 4.5 ms per 2^20 items); Falcon-512 runs four and gains nothing from it, so it keeps
-  // the smaller LDS footprint.
-  constexpr bool PAIRED = LOGN == 10 && !PREPARED;
-  __shared__ uint32_t s_buf2[PAIRED ? VERIFY_WAVES : 1][PAIRED ? G::XBUF : 1];
   static_assert(G::PKDW * 64 <= G::XBUF, "the key row fits the transpose buffer");
 
   fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);
@@ -657,12 +652,10 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
         //      lazily (equivalent to the reference's raw values). The row was loaded
         //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
         unpack_pkey<LOGN>(cur.pkw, cur.pal, pkb, lane, y);
-        if constexpr (PAIRED) {
-          ntt_forward2<LOGN>(x, y, T, buf, s_buf2[wave], lane);
-        } else {
-          ntt_forward<LOGN>(y, T, buf, lane);
-          ntt_forward<LOGN>(x, T, buf, lane);
-        }
+        // One transform after the other: interleaving them (ntt_forward2) costs Falcon-1024 its third wave per SIMD
+        // (31 more VGPRs, 17 KB more LDS) and, with the stages grouped by instruction kind, is 13 % slower.
+        ntt_forward<LOGN>(y, T, buf, lane);
+        ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) x[m] = mulmod_lazy(reduce(x[m]), y[m]);  // polynomial.hpp:99-110; |y| <= 16383 + 10q
       }
