@@ -236,10 +236,9 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   const bool live = slot < count;
   const uint32_t row = live ? slot : count - 1u;  // idle lanes shadow the last row and write nothing
 
-  // geometry of this lane's row, relative to the 16-byte aligned address `abase` at or below the body
+  // geometry of this lane's row, relative to the 16-byte aligned address at or below the body (`lbase` below)
   const uint8_t* body = sig + (size_t)row * SIGLEN + 41;
   const uint32_t boff = (uint32_t)((uintptr_t)body & 15u);
-  const uint4* abase = (const uint4*)(body - boff);  // derived from `sig` by pointer arithmetic only: global loads, not flat
   const uint32_t end_bits = 8u * (boff + BODY);        // first bit past the signature
   const uint32_t plast = (boff + BODY - 1u) >> 4;      // last piece holding a byte of the row (never read past it)
   uint32_t* myring = ring + lane * DF_RING_DW;
@@ -252,14 +251,14 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
     dst[-3] = __builtin_bswap32(v.w);
     if ((piece & 7u) == 0u) rowring[0] = __builtin_bswap32(v.x);  // mirror of index 32
   };
-  // the stream from bit p (relative to abase) on, MSB first, in the top 64 - (p & 31) bits
+  // the stream from bit p (relative to the aligned base) on, MSB first, in the top 64 - (p & 31) bits
   auto window64 = [&](uint32_t p) -> uint64_t {
     const uint32_t* src = myring + 31u - ((p >> 5) & 31u);  // {next dword, this dword}
     return (((uint64_t)src[1] << 32) | src[0]) << (p & 31u);
   };
   auto window = [&](uint32_t p) -> uint32_t { return (uint32_t)(window64(p) >> 32); };
 
-  uint32_t pos = 8u * boff;  // bit cursor relative to abase; body bit 0 == absolute bit 328 (decoding.hpp:276-277)
+  uint32_t pos = 8u * boff;  // bit cursor relative to the aligned base; body bit 0 == absolute bit 328 (decoding.hpp:276-277)
   uint32_t ld = 0;           // pieces [0, ld) have been put into the ring
   {  // prologue: pieces 0..5 of every row (enough for the first chunk), eight lanes per row
     uint4 v[8];
