@@ -169,11 +169,20 @@ int h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t xs, Pi
     }
   };
   std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, t);
+  unsigned started = 1;  // the calling thread is worker 0
+  try {
+    for (; started < nt; started++) pool.emplace_back(work, started);
+  } catch (...) {  // no exception crosses the C ABI: the workers that did start still cover every piece below
+  }
   work(0);
   for (auto& th : pool) th.join();
   for (int e : err)
     if (e) return e;
+  // pieces of workers that could not be started
+  for (unsigned t = started; t < nt; t++) {
+    work(t);
+    if (err[t]) return err[t];
+  }
   return 0;
 }
 
@@ -591,7 +600,7 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
   }
-  for (int t = 0; t < 2 && !rc; t++) {
+  for (int t = 0; t < 2 && !rc; t++) try {
     const Tables tb = make_tables(9 + t);
     const size_t bytes = tb.fwd.size() * sizeof(Tw);
     ctx->nc[t] = tb.nc;
@@ -604,6 +613,8 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMalloc((void**)&ctx->d_itwc[t], cbytes);
     if (!rc) rc = (int)hipMemcpy(ctx->d_twc[t], tb.fwdC.data(), cbytes, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(ctx->d_itwc[t], tb.invC.data(), cbytes, hipMemcpyHostToDevice);
+  } catch (...) {  // std::bad_alloc while building the tables
+    rc = FA_E_INTERNAL;
   }
   if (rc) {
     fa_ctx_destroy(ctx);
@@ -982,6 +993,7 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
   if (!logn || !pk || !pk_off || !msg_off || !sig || !sig_off || !accept) return FA_E_ARG;
   for (size_t i = 0; i < count; i++)
     if (logn[i] != 9 && logn[i] != 10) return FA_E_LOGN;
+  try {
   for (int ln = 9; ln <= 10; ln++) {  // partition by N on the host, one pass per class
     const size_t pklen = fa_pkey_len(ln), siglen = fa_sig_len(ln);
     std::vector<size_t> who;
@@ -1003,6 +1015,9 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
                                   gacc.data(), nullptr);
     if (rc) return rc;
     for (size_t k = 0; k < who.size(); k++) accept[who[k]] = gacc[k];
+  }
+  } catch (...) {  // std::bad_alloc of the host-side partition: no exception crosses the C ABI
+    return FA_E_INTERNAL;
   }
   return 0;
 }
