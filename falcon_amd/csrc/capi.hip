@@ -961,12 +961,16 @@ void fa_host_free(void* p)
 int fa_host_register(void* p, size_t bytes)
 {
   if (!p || bytes == 0) return FA_E_ARG;
-  return (int)hipHostRegister(p, bytes, hipHostRegisterDefault);
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) (void)hipGetLastError();  // reported here; must not linger as the "last error" of a later launch
+  return (int)e;
 }
 int fa_host_unregister(void* p)
 {
   if (!p) return FA_E_ARG;
-  return (int)hipHostUnregister(p);
+  const hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return (int)e;
 }
 
 int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg, const uint64_t* msg_off,

@@ -179,7 +179,8 @@ int fa_decode_sigs_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, 
 
 /* Pinned host memory for the host-buffer entry points (no reference counterpart: the reference never
  * leaves the CPU). fa_host_alloc returns NULL on failure; fa_host_register pins an existing range
- * (page-granular, costly: worth it only for buffers that are reused). */
+ * (page-granular, costly: worth it only for buffers that are reused; some hosts refuse it -- the MI355X boxes this
+ * was measured on return hipErrorInvalidValue -- and the memory then simply stays pageable). */
 void* fa_host_alloc(size_t bytes);
 void fa_host_free(void* p);
 int fa_host_register(void* p, size_t bytes);

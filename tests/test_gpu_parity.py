@@ -292,6 +292,15 @@ def test_host_pipeline_sub_batches(oracle, corpus, logn):
         assert out is bufs[3].array
         np.testing.assert_array_equal(out, want & 1)
         np.testing.assert_array_equal(c.verify_many(logn, pk2, msg2, sig2, norm_policy=1), (want >> 1) & 1)
+        # caller memory pinned in place (fa_host_register), then released again
+        # (hipHostRegister is refused with "invalid argument" on some hosts, this pool's boxes among them: the call
+        # then reports that error and the memory simply stays pageable)
+        if c.lib.fa_host_register(sig2.ctypes.data, sig2.nbytes) == 0:
+            try:
+                np.testing.assert_array_equal(c.verify_many(logn, pk2, msg2, sig2), want & 1)
+            finally:
+                assert c.lib.fa_host_unregister(sig2.ctypes.data) == 0
+        assert c.lib.fa_host_register(None, 16) != 0 and c.lib.fa_host_unregister(None) != 0
         # prepared keys: one per item, then a few shared ones named by index
         prep = c.prepare_keys(logn, pk=pk2)
         np.testing.assert_array_equal(c.verify_many_prepared(logn, prep, msg2, sig2), want & 1)
