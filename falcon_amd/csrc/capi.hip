@@ -208,6 +208,8 @@ struct fa_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_ready[2] = { nullptr, nullptr };  // staging set k is filled
   uint32_t host_chunk = 1u << 17;  // items per sub-batch of the host-buffer pipeline
+  int wire = FA_WIRE_REFERENCE;    // wire format of keys and signatures (FA_OPT_WIRE_FORMAT)
+  DevBuf spec_pk;                  // FA_WIRE_SPEC: the batch's keys repacked into the reference's form
   bool overlap = true;
   Tw* d_tw[2] = { nullptr, nullptr };
   Tw* d_itw[2] = { nullptr, nullptr };
@@ -266,6 +268,26 @@ int timed(fa_ctx* ctx, hipStream_t s, int kind, F&& launch)
 
 bool aligned4(const void* p) { return ((uintptr_t)p & 3u) == 0; }
 
+// FA_WIRE_SPEC: repack `count` specification-format public keys into the reference's form in the context's
+// buffer and return that; FA_WIRE_REFERENCE: the keys as they are.
+int keys_in_reference_form(fa_ctx* ctx, int logn, hipStream_t s, const uint8_t* pk, size_t count, const uint8_t** out)
+{
+  *out = pk;
+  if (ctx->wire != FA_WIRE_SPEC || !pk || count == 0) return 0;
+  const size_t pklen = logn == 9 ? 897 : 1793;
+  int rc = ctx->spec_pk.reserve(count * pklen + 8);
+  if (rc) return rc;
+  const uint32_t n = (uint32_t)count;
+  const uint32_t grid = std::min<uint32_t>((n + 3) / 4, (uint32_t)ctx->num_cu * 16u);
+  if (logn == 9)
+    hipLaunchKernelGGL(pk_spec_to_ref_kernel<9>, dim3(grid), dim3(256), 0, s, pk, (uint8_t*)ctx->spec_pk.p, n);
+  else
+    hipLaunchKernelGGL(pk_spec_to_ref_kernel<10>, dim3(grid), dim3(256), 0, s, pk, (uint8_t*)ctx->spec_pk.p, n);
+  HIP_TRY(hipGetLastError());
+  *out = (const uint8_t*)ctx->spec_pk.p;
+  return 0;
+}
+
 // The signature decoders over `slots` consecutive rows of `sig`, into the context's workspace (s2 tiled,
 // sqn, st2): the fast decoder, then the generic one on the items it queued (those that met the k >= 8 rule).
 // The fix-up pass is one lane per queued item, a few hundred latency-bound waves at most; with `fork` it runs
@@ -287,7 +309,7 @@ int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig,
   HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
   rc = timed(ctx, s, 0, [&] {
     hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
-                       d_st2, d_cnt, d_list);
+                       d_st2, d_cnt, d_list, (uint32_t)(ctx->wire == FA_WIRE_SPEC));
   });
   if (rc) return rc;
   hipStream_t ds = fork ? ctx->aux : s;
@@ -297,7 +319,8 @@ int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig,
   }
   rc = timed(ctx, ds, 0, [&] {
     hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, ds, sig,
-                       (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2);
+                       (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2,
+                       (uint32_t)(ctx->wire == FA_WIRE_SPEC));
   });
   if (!rc && fork) rc = (int)hipEventRecord(ctx->ev_join, ds);
   return rc;
@@ -327,7 +350,7 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   if (idx) {  // re-hash pass: a handful of items, the generic decoder is enough
     rc = timed(ctx, s, 0, [&] {
       hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
-                         slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2);
+                         slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2, (uint32_t)(ctx->wire == FA_WIRE_SPEC));
     });
   } else {
     rc = decode_stage<LOGN>(ctx, s, slots, sig, ctx->overlap);
@@ -361,6 +384,7 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   A.retry_count = (uint32_t*)ctx->retry_count.p;
   A.retry_list = (uint32_t*)ctx->retry_list.p;
   A.item_base = item_base;
+  A.half = ctx->wire == FA_WIRE_SPEC ? Q / 2u + 1u : Q / 2u;
   A.dbg = dbg;
   const uint32_t want = (slots + VERIFY_WAVES - 1) / VERIFY_WAVES;
   const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * 8u);
@@ -642,7 +666,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
   }
   DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->slow_count, &ctx->slow_list, &ctx->h_pk,
-                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_a, &ctx->h_b, &ctx->h_c };
+                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->spec_pk };
   for (DevBuf* b : bufs) b->release();
   for (auto& st : ctx->hs) {
     DevBuf* sb[] = { &st.pk, &st.sig, &st.msg, &st.off, &st.kidx, &st.accept };
@@ -684,6 +708,10 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
     case FA_OPT_HOST_CHUNK_ITEMS:
       if (value < 64 || value > (1 << 24)) return FA_E_ARG;
       ctx->host_chunk = (uint32_t)value;
+      return 0;
+    case FA_OPT_WIRE_FORMAT:
+      if (value != FA_WIRE_REFERENCE && value != FA_WIRE_SPEC) return FA_E_ARG;
+      ctx->wire = (int)value;
       return 0;
     case FA_OPT_HOST_THREADS:
       if (value < 0 || value > 64) return FA_E_ARG;
@@ -730,7 +758,8 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
   KeySrc keys;
-  keys.pk = pk;
+  const int rc = keys_in_reference_form(ctx, logn, s, pk, count, &keys.pk);
+  if (rc) return rc;
   return logn == 9 ? verify_dev<9>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
                    : verify_dev<10>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
 }
@@ -771,6 +800,10 @@ int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, 
   const int T = logn - 9;
   const uint32_t n = (uint32_t)nkeys;
   const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  {
+    const int rc = keys_in_reference_form(ctx, logn, s, pk, nkeys, &pk);
+    if (rc) return rc;
+  }
 #define FA_LAUNCH_PREP(LN, PACKED)                                                                                      \
   hipLaunchKernelGGL((prepare_keys_kernel<LN, PACKED>), dim3(grid), dim3(VERIFY_WG), 0, s, pk, h, n, prepared,           \
                      ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
@@ -909,8 +942,12 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     HIP_TRY(hipEventRecord(ctx->ev_ready[k & 1], xs));
     return 0;
   };
-  auto launch = [&](size_t k, const Sub& S) -> int {
+  auto launch = [&](size_t k, Sub& S) -> int {
     HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_ready[k & 1], 0));
+    if (S.keys.pk) {  // FA_WIRE_SPEC: this sub-batch's keys, repacked on the compute stream (one buffer: sub-batches run in turn)
+      const int r = keys_in_reference_form(ctx, logn, cs, S.keys.pk, S.cnt, &S.keys.pk);
+      if (r) return r;
+    }
     const fa_debug* dp = dbg ? &S.d : nullptr;
     return logn == 9 ? verify_enqueue<9>(ctx, S.cnt, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs)
                      : verify_enqueue<10>(ctx, S.cnt, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs);
@@ -1180,6 +1217,10 @@ int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, 
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n = (uint32_t)count;
   const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  {
+    const int rc = keys_in_reference_form(ctx, logn, s, pk, count, &pk);
+    if (rc) return rc;
+  }
   if (logn == 9)
     hipLaunchKernelGGL(decode_pkeys_kernel<9>, dim3(grid), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
   else

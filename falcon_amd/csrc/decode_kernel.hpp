@@ -107,7 +107,7 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
                                                            const uint32_t* __restrict__ idx, uint32_t count,
                                                            const uint32_t* __restrict__ dcount, bool scatter,
                                                            uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
-                                                           uint8_t* __restrict__ st)
+                                                           uint8_t* __restrict__ st, uint32_t spec)
 {
   constexpr int N = 1 << LOGN;
   constexpr int SIGLEN = LOGN == 9 ? 666 : 1280;
@@ -148,6 +148,24 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
         mag += k << 7;
         br.skip(9 + (int32_t)k);
         pos += 9 + (int32_t)k;
+      } else if (spec) {  // specification (Algorithm 18): the unary run simply goes on, at most 15 zeros (|s| <= 2047)
+        br.skip(16);
+        pos += 16;
+        uint32_t kk = 8u;
+        bool term = false;
+        while (!term && pos < SLEN && kk <= 15u) {
+          br.refill();
+          term = (br.peek32() >> 31) != 0u;
+          br.skip(1);
+          pos += 1;
+          if (!term) kk++;
+        }
+        if (!term) {  // ran out of bits or more than 15 zeros
+          failed = true;
+          stop = true;
+          continue;
+        }
+        mag += kk << 7;
       } else {  // decoding.hpp:300-320: skip whole windows until one holds a 1 or the stream ends
         br.skip(16);
         pos += 16;
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
       make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
   }
 
-  failed |= (pos >= SLEN) | (i < N);  // decoding.hpp:340
+  failed |= (spec ? pos > SLEN : pos >= SLEN) | (i < N);  // decoding.hpp:340; the specification lets the last code end on the last bit
   if (!failed) {  // decoding.hpp:342-357: the rest of the stream must be zero
     while (pos < SLEN) {
       br.refill();
@@ -221,7 +239,7 @@ template <int LOGN>
 __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restrict__ sig, uint32_t count,
                                                          uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
                                                          uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
-                                                         uint32_t* __restrict__ slow_list)
+                                                         uint32_t* __restrict__ slow_list, uint32_t spec)
 {
   constexpr int N = 1 << LOGN;
   constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
     return;
   }
   // Trailing bits (decoding.hpp:342-357) are checked from the ring, which holds the row up to piece ld.
-  const bool past_end = pos >= end_bits;                              // decoding.hpp:340
+  const bool past_end = spec ? pos > end_bits : pos >= end_bits;      // decoding.hpp:340 (the specification allows ==)
   const bool tail_missing = !past_end && end_bits > 128u * ld;        // tail longer than the ring holds: rare
   if (maxk == 8u || tail_missing) {                                   // needs the generic decoder
     st[slot] = ST_BAD_ENCODING;  // overwritten by the fix-up pass

@@ -411,6 +411,7 @@ struct VerifyArgs {
   uint32_t nblk;
   uint32_t wrap32;          // norm policy
   uint32_t item_base;       // added to item in retry_list entries (chunked main pass)
+  uint32_t half;            // s1 values >= half are negative: 6144 as the reference centres (verification.hpp:59-68), 6145 as the specification does
   uint8_t* accept;          // [items]
   uint32_t* retry_count;    // items whose hash needs more blocks
   uint32_t* retry_list;
@@ -668,12 +669,12 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
         const uint32_t i = idxA<LOGN>(lane, m);
         const uint32_t craw = cbuf[i];                              // < 61445
         const uint32_t r0 = (uint32_t)reduce((int32_t)craw - x[m]); // s1 in [0, q] (x[m] in [0, q])
-        const uint32_t mag = r0 >= Q / 2u ? Q - r0 : r0;            // |centred s1|, verification.hpp:59-68 (q -> 0)
+        const uint32_t mag = r0 >= A.half ? Q - r0 : r0;            // |centred s1|, verification.hpp:59-68 (q -> 0)
         acc += mul24(mag, mag);
         const uint32_t r = DEBUG ? csub(r0, Q) : r0;                // canonical s1, debug output only
         if (DEBUG) {
           if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
-          if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= Q / 2u ? (int32_t)r - (int32_t)Q : (int32_t)r);
+          if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= A.half ? (int32_t)r - (int32_t)Q : (int32_t)r);
           if (A.dbg.s2) {
             const uint32_t v = cur.s2v[m];
             A.dbg.s2[(size_t)item * N + i] = (int16_t)(v > Q / 2u ? (int32_t)v - (int32_t)Q : (int32_t)v);
@@ -855,6 +856,40 @@ __global__ __launch_bounds__(VERIFY_WG) void decode_pkeys_kernel(const uint8_t* 
     for (int m = 0; m < R; m++) h[(size_t)key * N + idxA<LOGN>(lane, m)] = good ? (uint16_t)y[m] : (uint16_t)0;
     if (lane == 0) ok[key] = good ? 1 : 0;
     wave_lds_sync();
+  }
+}
+
+// ---- specification wire format, public keys (FA_WIRE_SPEC; no counterpart in the reference, README.md:74-75) ----
+// Falcon specification section 3.11.4: header 0x00 | logn, then n 14-bit fields packed most significant bit first,
+// each < q. Four fields are 7 bytes in either packing, so a key is repacked group by group into the reference's
+// little-endian form (decoding.hpp:34-45) and the pipeline runs unchanged on the result. A key with a field >= q
+// (invalid in the specification) gets header 0xff, which the pipeline rejects like any wrong header. One wave per
+// key, lane L takes groups L, L + 64, ...
+template <int LOGN>
+__global__ __launch_bounds__(256) void pk_spec_to_ref_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t nkeys)
+{
+  constexpr uint32_t N = 1u << LOGN, PKLEN = 1u + 14u * N / 8u, GROUPS = N / 4u;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t key = blockIdx.x * 4u + (threadIdx.x >> 6); key < nkeys; key += gridDim.x * 4u) {
+    const uint8_t* src = in + (size_t)key * PKLEN;
+    uint8_t* dst = out + (size_t)key * PKLEN;
+    bool ok = true;
+    for (uint32_t g = lane; g < GROUPS; g += 64u) {
+      unsigned long long v = 0;
+#pragma unroll
+      for (int b = 0; b < 7; b++) v = (v << 8) | src[1u + 7u * g + b];
+      unsigned long long w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t c = (uint32_t)(v >> (14 * (3 - j))) & 0x3fffu;
+        ok &= c < Q;
+        w |= (unsigned long long)c << (14 * j);
+      }
+#pragma unroll
+      for (int b = 0; b < 7; b++) dst[1u + 7u * g + b] = (uint8_t)(w >> (8 * b));
+    }
+    const bool all_ok = __ballot(!ok) == 0ull;
+    if (lane == 0) dst[0] = all_ok ? src[0] : (uint8_t)0xff;
   }
 }
 

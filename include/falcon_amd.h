@@ -50,6 +50,18 @@ extern "C" {
 #define FA_OPT_HOST_CHUNK_ITEMS 6 /* items per sub-batch of the host-buffer pipeline (copy/compute overlap), default 2^17 */
 #define FA_OPT_HOST_THREADS 7    /* host threads that stage pageable caller memory through pinned buffers, default 6; 0: the runtime's own path */
 
+#define FA_OPT_WIRE_FORMAT 8     /* FA_WIRE_REFERENCE (default) or FA_WIRE_SPEC, see below */
+
+/* Wire format of public keys and signatures, for every entry point that parses them (verify, prepare_keys from
+ * encoded keys, decode_pkeys, decode_sigs). The reference is not wire compatible with the Falcon specification
+ * (README.md:74-75); REFERENCE reproduces it bit for bit and is what every parity claim refers to. SPEC reads the
+ * specification's formats instead (falcon-sign.info/falcon.pdf: 14-bit big-endian key fields, each < q; Algorithm 18
+ * Decompress with |s| <= 2047; a code may end on the last bit) and centres s1 to [-6144, 6144] as the specification
+ * does (the reference maps 6144 to -6145, verification.hpp:59-68). SPEC has no counterpart in the reference and no
+ * known-answer vector was available to pin it: it is held only to this repository's own restatements. */
+#define FA_WIRE_REFERENCE 0
+#define FA_WIRE_SPEC 1
+
 typedef struct fa_ctx fa_ctx;
 
 /* Debug outputs: the intermediates of verification.hpp:20-80. Any pointer may be NULL. Arrays are

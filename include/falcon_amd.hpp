@@ -92,6 +92,16 @@ inline fa_ctx* context(int device)
 
 }  // namespace detail
 
+// Wire format of keys and signatures for this thread's context on `device` (FA_OPT_WIRE_FORMAT): `reference`, the
+// default, is the reference's own format and rules; `spec` reads the Falcon specification's formats instead, which
+// the reference does not (README.md:74-75) -- no counterpart there, see falcon_amd.h.
+enum class wire_format : int { reference = FA_WIRE_REFERENCE, spec = FA_WIRE_SPEC };
+inline void set_wire_format(wire_format w, int device = 0)
+{
+  const int rc = fa_set_option(detail::context(device), FA_OPT_WIRE_FORMAT, (int)w);
+  if (rc) throw device_error("fa_set_option", rc);
+}
+
 // Record sizes, utils.hpp:9-17 and :39-49.
 template<size_t N> constexpr size_t pkey_len() { return 1 + 14 * N / 8; }
 template<size_t N> constexpr size_t sig_len() { return N == 512 ? 666 : 1280; }

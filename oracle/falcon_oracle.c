@@ -456,6 +456,99 @@ int fo_decode_sig(unsigned logn, const uint8_t* sig, uint8_t* salt, int32_t* s2)
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Specification wire format (the optional mode).                 */
+/* The reference is NOT wire compatible with the Falcon specification (README.md:74-75):  */
+/* these functions have no counterpart in it. They restate falcon-sign.info/falcon.pdf    */
+/* (v1.2): section 3.11.4 (public key: header 0x00 | logn, then 14-bit big-endian fields, */
+/* each < q), Algorithm 17 Compress / Algorithm 18 Decompress (sign, 7 low bits, unary    */
+/* high part; -0, an unterminated code, non-zero padding are invalid) with the bound      */
+/* |s| <= 2047 of the specification's reference code. PARITY UNPINNED: no official         */
+/* known-answer vector is available offline; tests hold them to an independent Python      */
+/* restatement and to encode/decode round trips only.                                      */
+/* ------------------------------------------------------------------------------------ */
+
+int fo_spec_decode_pkey(unsigned logn, const uint8_t* pkey, uint16_t* h)
+{
+  const size_t n = (size_t)1 << logn;
+  int ok = pkey[0] == (uint8_t)logn;
+  for (size_t g = 0; g < n / 4 && ok; g++) { /* 4 fields = 56 bits = 7 bytes, most significant bit first */
+    uint64_t v = 0;
+    for (int b = 0; b < 7; b++) v = (v << 8) | pkey[1 + 7 * g + (size_t)b];
+    for (int j = 0; j < 4; j++) {
+      const uint16_t c = (uint16_t)((v >> (14 * (3 - j))) & 0x3fff);
+      if (c >= FO_Q) ok = 0;
+      h[4 * g + (size_t)j] = c;
+    }
+  }
+  if (!ok) memset(h, 0, 2 * n);
+  return ok;
+}
+
+void fo_spec_encode_pkey(unsigned logn, const uint16_t* h, uint8_t* pkey)
+{
+  const size_t n = (size_t)1 << logn;
+  pkey[0] = (uint8_t)logn;
+  for (size_t g = 0; g < n / 4; g++) {
+    uint64_t v = 0;
+    for (int j = 0; j < 4; j++) v = (v << 14) | (uint64_t)(h[4 * g + (size_t)j] & 0x3fff);
+    for (int b = 0; b < 7; b++) pkey[1 + 7 * g + (size_t)b] = (uint8_t)(v >> (8 * (6 - b)));
+  }
+}
+
+static inline unsigned spec_bit(const uint8_t* sig, size_t bit) { return (sig[bit >> 3] >> (7 - (bit & 7u))) & 1u; }
+
+/* Algorithm 18. Body = bits 328 .. 8*sbytelen - 1 of sig. */
+int fo_spec_decompress_sig(unsigned logn, const uint8_t* sig, int32_t* poly_s)
+{
+  const size_t n = (size_t)1 << logn, slen = 8 * fo_sig_len(logn);
+  size_t bit = 8 + 320;
+  int failed = 0;
+  for (size_t i = 0; i < n && !failed; i++) {
+    if (bit + 8 > slen) { failed = 1; break; }
+    const unsigned sign = spec_bit(sig, bit);
+    int32_t low = 0;
+    for (int b = 1; b < 8; b++) low = (low << 1) | (int32_t)spec_bit(sig, bit + (size_t)b);
+    bit += 8;
+    int32_t k = 0;
+    for (;;) {
+      if (bit >= slen) { failed = 1; break; }
+      if (spec_bit(sig, bit++)) break;
+      if (++k > 15) { failed = 1; break; } /* |s| <= 2047 */
+    }
+    if (failed) break;
+    const int32_t mag = low + 128 * k;
+    if (sign && mag == 0) { failed = 1; break; } /* -0 */
+    poly_s[i] = sign ? -mag : mag;
+  }
+  for (; bit < slen && !failed; bit++) failed |= (int)spec_bit(sig, bit); /* padding must be zero */
+  if (failed) memset(poly_s, 0, sizeof(int32_t) * n);
+  return !failed;
+}
+
+/* Algorithm 17. Writes bytes 41.. of sig (zero padded); returns 0 when the code does not fit. */
+int fo_spec_compress_sig(unsigned logn, const int32_t* poly_s, uint8_t* sig)
+{
+  const size_t n = (size_t)1 << logn, sbytelen = fo_sig_len(logn), slen = 8 * sbytelen;
+  size_t bit = 8 + 320;
+  memset(sig + 41, 0, sbytelen - 41);
+  for (size_t i = 0; i < n; i++) {
+    const int32_t v = poly_s[i], mag = v < 0 ? -v : v;
+    const size_t k = (size_t)(mag >> 7), need = 9 + k;
+    if (mag > 2047 || bit + need > slen) {
+      memset(sig + 41, 0, sbytelen - 41);
+      return 0;
+    }
+    const uint32_t code = ((uint32_t)(v < 0) << 7) | (uint32_t)(mag & 0x7f);
+    for (int b = 0; b < 8; b++, bit++)
+      if ((code >> (7 - b)) & 1u) sig[bit >> 3] |= (uint8_t)(0x80u >> (bit & 7u));
+    bit += k;
+    sig[bit >> 3] |= (uint8_t)(0x80u >> (bit & 7u));
+    bit++;
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* verify, verification.hpp:20-80 and falcon.hpp:230-249                                  */
 /* ------------------------------------------------------------------------------------ */
 
@@ -473,9 +566,12 @@ typedef struct {
 
 static const int32_t FO_BETA2[2] = { 34034726, 70265242 }; /* falcon.hpp:245 */
 
-/* Returns bit0 = accept under exact64, bit1 = accept under wrap32. dbg may be NULL. */
-int fo_verify(unsigned logn, const uint8_t* pkey, const uint8_t* msg, size_t mlen, const uint8_t* sig,
-              fo_debug* dbg)
+/* Returns bit0 = accept under exact64, bit1 = accept under wrap32. dbg may be NULL.
+ * wire 0: the reference's formats and rules (every line below cites it). wire 1: the specification's wire
+ * format (codecs above) and its centring of s1 to [-(q-1)/2, (q-1)/2] -- the reference maps 6144 to -6145
+ * (verification.hpp:59-68), the specification keeps it at +6144; everything else is shared. */
+int fo_verify_wire(unsigned logn, int wire, const uint8_t* pkey, const uint8_t* msg, size_t mlen, const uint8_t* sig,
+                   fo_debug* dbg)
 {
   const size_t n = (size_t)1 << logn;
   uint16_t h[1024], c[1024], s2n[1024], s1[1024];
@@ -484,11 +580,17 @@ int fo_verify(unsigned logn, const uint8_t* pkey, const uint8_t* msg, size_t mle
   pthread_once(&g_once, init_tables);
   if (dbg) memset(dbg, 0, sizeof(*dbg));
 
-  if (!fo_decode_pkey(logn, pkey, h)) { /* falcon.hpp:240-243 */
+  if (!(wire ? fo_spec_decode_pkey(logn, pkey, h) : fo_decode_pkey(logn, pkey, h))) { /* falcon.hpp:240-243 */
     if (dbg) dbg->status = FO_BAD_PK_HEADER;
     return 0;
   }
-  const int dec = fo_decode_sig(logn, sig, salt, s2); /* verification.hpp:31-34 */
+  int dec;
+  if (wire) {
+    dec = sig[0] != (uint8_t)(0x30 | logn) ? 0 : fo_spec_decompress_sig(logn, sig, s2) ? 1 : -1;
+    if (dec == 1) memcpy(salt, sig + 1, 40);
+  } else {
+    dec = fo_decode_sig(logn, sig, salt, s2); /* verification.hpp:31-34 */
+  }
   if (dec != 1) {
     if (dbg) dbg->status = dec == 0 ? FO_BAD_SIG_HEADER : FO_BAD_ENCODING;
     return 0;
@@ -512,7 +614,7 @@ int fo_verify(unsigned logn, const uint8_t* pkey, const uint8_t* msg, size_t mle
   uint64_t norm = 0;
   for (size_t i = 0; i < n; i++) norm += (uint64_t)((int64_t)s2[i] * s2[i]); /* :72-74 */
   for (size_t i = 0; i < n; i++) {
-    const int32_t v = (int32_t)s1[i] - (s1[i] >= FO_Q / 2) * (int32_t)FO_Q; /* :59-68 */
+    const int32_t v = (int32_t)s1[i] - (s1[i] >= FO_Q / 2 + (unsigned)(wire != 0)) * (int32_t)FO_Q; /* :59-68 */
     if (dbg) dbg->s1[i] = (int16_t)v;
     norm += (uint64_t)((int64_t)v * v);                                     /* :75-77 */
   }
@@ -525,6 +627,12 @@ int fo_verify(unsigned logn, const uint8_t* pkey, const uint8_t* msg, size_t mle
     dbg->status = ok_exact ? FO_OK : FO_NORM_TOO_LARGE;
   }
   return ok_exact | (ok_wrap << 1);
+}
+
+int fo_verify(unsigned logn, const uint8_t* pkey, const uint8_t* msg, size_t mlen, const uint8_t* sig,
+              fo_debug* dbg)
+{
+  return fo_verify_wire(logn, 0, pkey, msg, mlen, sig, dbg);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -541,6 +649,7 @@ typedef struct {
   size_t mlen;
   uint8_t* flags;
   fo_debug* dbg;
+  int wire;
 } fo_job;
 
 static void* fo_worker(void* arg)
@@ -550,15 +659,15 @@ static void* fo_worker(void* arg)
   for (size_t i = j->begin; i < j->end; i++) {
     const uint8_t* m = j->msg_off ? j->msg + j->msg_off[i] : j->msg + i * j->mlen;
     const size_t ml = j->msg_off ? (size_t)(j->msg_off[i + 1] - j->msg_off[i]) : j->mlen;
-    j->flags[i] = (uint8_t)fo_verify(j->logn, j->pk + i * pklen, m, ml, j->sig + i * siglen,
-                                     j->dbg ? j->dbg + i : NULL);
+    j->flags[i] = (uint8_t)fo_verify_wire(j->logn, j->wire, j->pk + i * pklen, m, ml, j->sig + i * siglen,
+                                          j->dbg ? j->dbg + i : NULL);
   }
   return NULL;
 }
 
-void fo_verify_many(unsigned logn, size_t count, const uint8_t* pk, const uint8_t* msg,
-                    const uint64_t* msg_off, size_t mlen, const uint8_t* sig, uint8_t* flags,
-                    fo_debug* dbg, int threads)
+void fo_verify_many_wire(unsigned logn, int wire, size_t count, const uint8_t* pk, const uint8_t* msg,
+                         const uint64_t* msg_off, size_t mlen, const uint8_t* sig, uint8_t* flags,
+                         fo_debug* dbg, int threads)
 {
   if (threads < 1) threads = 1;
   if ((size_t)threads > count) threads = count ? (int)count : 1;
@@ -566,13 +675,20 @@ void fo_verify_many(unsigned logn, size_t count, const uint8_t* pk, const uint8_
   fo_job* jobs = (fo_job*)malloc(sizeof(fo_job) * (size_t)threads);
   for (int t = 0; t < threads; t++) {
     jobs[t] = (fo_job){ logn, count * (size_t)t / (size_t)threads, count * (size_t)(t + 1) / (size_t)threads,
-                        pk, msg, sig, msg_off, mlen, flags, dbg };
+                        pk, msg, sig, msg_off, mlen, flags, dbg, wire };
     if (t > 0) pthread_create(&th[t], NULL, fo_worker, &jobs[t]);
   }
   fo_worker(&jobs[0]);
   for (int t = 1; t < threads; t++) pthread_join(th[t], NULL);
   free(th);
   free(jobs);
+}
+
+void fo_verify_many(unsigned logn, size_t count, const uint8_t* pk, const uint8_t* msg,
+                    const uint64_t* msg_off, size_t mlen, const uint8_t* sig, uint8_t* flags,
+                    fo_debug* dbg, int threads)
+{
+  fo_verify_many_wire(logn, 0, count, pk, msg, msg_off, mlen, sig, flags, dbg, threads);
 }
 
 size_t fo_debug_size(void) { return sizeof(fo_debug); }

@@ -70,6 +70,13 @@ class Oracle:
         lib.fo_decode_pkey.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_uint16)]
         lib.fo_decompress_sig.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_int32)]
         lib.fo_decode_sig.argtypes = [ctypes.c_uint, _u8p, _u8p, ctypes.POINTER(ctypes.c_int32)]
+        lib.fo_spec_decode_pkey.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_uint16)]
+        lib.fo_spec_encode_pkey.argtypes = [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint16), _u8p]
+        lib.fo_spec_decompress_sig.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_int32)]
+        lib.fo_spec_compress_sig.argtypes = [ctypes.c_uint, ctypes.POINTER(ctypes.c_int32), _u8p]
+        lib.fo_verify_many_wire.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_size_t, _u8p, _u8p,
+                                            ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, _u8p, _u8p, ctypes.c_void_p,
+                                            ctypes.c_int]
         for f in (lib.fo_ntt, lib.fo_intt):
             f.argtypes = [ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint]
             f.restype = None
@@ -114,6 +121,32 @@ class Oracle:
         ok = self.lib.fo_decode_sig(logn, _p(sig), _p(salt), _p(s2, ctypes.c_int32))
         return ok == 1, salt, s2  # 0: wrong header, -1: body does not decode
 
+    # ---- specification wire format (no counterpart in the reference; oracle/falcon_oracle.c "Specification wire format") ----
+    def spec_decode_pkey(self, logn, pk):
+        pk = np.ascontiguousarray(pk, np.uint8)
+        h = np.zeros(1 << logn, np.uint16)
+        return bool(self.lib.fo_spec_decode_pkey(logn, _p(pk), _p(h, ctypes.c_uint16))), h
+
+    def spec_encode_pkey(self, logn, h):
+        h = np.ascontiguousarray(h, np.uint16)
+        pk = np.zeros(pk_len(logn), np.uint8)
+        self.lib.fo_spec_encode_pkey(logn, _p(h, ctypes.c_uint16), _p(pk))
+        return pk
+
+    def spec_decompress_sig(self, logn, sig):
+        sig = np.ascontiguousarray(sig, np.uint8)
+        s = np.zeros(1 << logn, np.int32)
+        return bool(self.lib.fo_spec_decompress_sig(logn, _p(sig), _p(s, ctypes.c_int32))), s
+
+    def spec_compress_sig(self, logn, s2, header_and_salt=None):
+        """Returns (fits, sig): bytes 41.. hold the code; bytes 0..40 are header_and_salt when given."""
+        s2 = np.ascontiguousarray(s2, np.int32)
+        sig = np.zeros(sig_len(logn), np.uint8)
+        ok = bool(self.lib.fo_spec_compress_sig(logn, _p(s2, ctypes.c_int32), _p(sig)))
+        if header_and_salt is not None:
+            sig[:41] = header_and_salt
+        return ok, sig
+
     def ntt(self, a, logn):
         a = np.array(a, np.uint16)
         self.lib.fo_ntt(_p(a, ctypes.c_uint16), logn)
@@ -149,9 +182,10 @@ class Oracle:
         r = self.lib.fo_verify(logn, _p(pk), _p(m), msg.size, _p(sig), d.ctypes.data)
         return r, d[0]
 
-    def verify_many(self, logn, pk, msg, sig, mlen=None, msg_off=None, debug=False, threads=1):
+    def verify_many(self, logn, pk, msg, sig, mlen=None, msg_off=None, debug=False, threads=1, wire=0):
         """Batch. pk/sig: (count, len) uint8; msg: (count, mlen) or flat bytes with msg_off[count+1].
-        Returns flags (count,) uint8 [bit0 exact64, bit1 wrap32] and the debug records (or None)."""
+        Returns flags (count,) uint8 [bit0 exact64, bit1 wrap32] and the debug records (or None).
+        wire=1: the specification's wire format instead of the reference's."""
         pk = np.ascontiguousarray(pk, np.uint8)
         sig = np.ascontiguousarray(sig, np.uint8)
         msg = np.ascontiguousarray(msg, np.uint8)
@@ -166,8 +200,8 @@ class Oracle:
         m = msg if msg.size else np.zeros(1, np.uint8)
         flags = np.zeros(count, np.uint8)
         dbg = np.zeros(count, _DBG_DTYPE) if debug else None
-        self.lib.fo_verify_many(logn, count, _p(pk), _p(m), _p(off, ctypes.c_uint64) if off is not None else None,
-                                mlen, _p(sig), _p(flags), dbg.ctypes.data if debug else None, threads)
+        self.lib.fo_verify_many_wire(logn, wire, count, _p(pk), _p(m), _p(off, ctypes.c_uint64) if off is not None else None,
+                                     mlen, _p(sig), _p(flags), dbg.ctypes.data if debug else None, threads)
         return flags, dbg
 
 
@@ -262,6 +296,23 @@ class Reference:
         norm = self.lib.fr_verify_after_hash(logn, _p(h, ctypes.c_uint16), _p(c, ctypes.c_uint16), _p(s2, ctypes.c_int32),
                                              _p(s1, ctypes.c_int16))
         return s1, int(norm)
+
+
+def to_spec_format(logn, pk, sig, orc=None):
+    """Re-encodes reference-format items in the specification's wire format: keys field by field (values >= q stay
+    as they are, which the specification rejects), signatures that decode through Algorithm 17; signatures the
+    reference decoder rejects keep their bytes (arbitrary input for the other decoder)."""
+    orc = orc or oracle()
+    spk, ssig = np.zeros_like(pk), sig.copy()
+    for i in range(pk.shape[0]):
+        ok, h = orc.decode_pkey(logn, pk[i])
+        spk[i] = orc.spec_encode_pkey(logn, h) if ok else pk[i]
+        ok, _, s2 = orc.decode_sig(logn, sig[i])
+        if ok:
+            fits, enc = orc.spec_compress_sig(logn, s2, sig[i][:41])
+            assert fits
+            ssig[i] = enc
+    return spk, ssig
 
 
 _oracle = None
