@@ -517,9 +517,25 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
     const uint32_t d = t * 64u + lane;
     r.hw[t] = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are always rejected
   }
-  const uint16_t* s2row = A.s2 + s2_tile_offset<LOGN>(slot, 0u);  // tiled: chunk stride 64*32, see decode_kernel.hpp
+  // s2 is tiled (chunk stride 64*32, see decode_kernel.hpp): coefficient i = 64 m + lane sits at row base + m * 4096 +
+  // (lane >> 5) * 2048 + (lane & 31). The per-m bases are wave-uniform: a load should be SGPR base + one VGPR offset
+  // shared by all m. Left alone hipcc adds the lane offset to the row base first and then builds eight 64-bit
+  // addresses with vector adds; the empty asm pins each base to an SGPR pair before the offset is added (it emits nothing).
+  const uint16_t* s2row = A.s2 + s2_tile_offset<LOGN>(slot, 0u);
+  if constexpr (LOGN == 9) {
+    uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes: a 32-bit byte offset is what the load takes
+    asm volatile("" : "+v"(lane_off));  // keeps its zero extension in this basic block, where instruction selection can fold it
 #pragma unroll
-  for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];  // i = 64 m + lane
+    for (int m = 0; m < G::R; m++) {
+      const uint16_t* base_m = s2row + (size_t)m * 4096u;
+      asm volatile("" : "+s"(base_m));
+      typedef const char __attribute__((address_space(1))) * global_bytes;  // still global memory after the asm: global_load, not flat_load
+      r.s2v[m] = *(const uint16_t __attribute__((address_space(1)))*)((global_bytes)base_m + lane_off);
+    }
+  } else {  // Falcon-1024 has no SGPRs to spare for 16 bases (they spill to VGPR lanes, measured +1 %): the compiler's way
+#pragma unroll
+    for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];
+  }
   if constexpr (PREPARED) {
     uint32_t key = A.key_idx ? A.key_idx[r.item] : A.item_base + r.item;
     key = __builtin_amdgcn_readfirstlane(key);
