@@ -212,8 +212,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
-        # Falcon-1024 with the malformed mix (BASELINE.json configs[3]) at 2^18 items
-        ne = 1 << 18
+        # Falcon-1024 with the malformed mix (BASELINE.json configs[3]) at its full 2^20 items
+        ne = min(n_items, 1 << 20)
         pk2, msg2, sig2, kinds = support.corpus().generate(10, ne, seed=0xFA1C1024, mlen=32, malformed_permille=250,
                                                            threads=threads)
         e_pk, e_msg, e_sig = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (pk2, msg2, sig2))
@@ -236,7 +236,7 @@ def main():
             "accepted_fraction": float(e_acc.float().mean().item()),
             "accept_mismatches_vs_oracle_first_16384": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum())}
         # mixed Falcon-512 + Falcon-1024 batch (BASELINE.json configs[4], one GPU's share): the batch is split by N
-        # and runs as one pass per class; 2^18 items of each class here
+        # and runs as one pass per class; `ne` items of each class here
         if logn == 9:
             def step_mixed():
                 ctx.verify_many_dev(9, ne, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
