@@ -55,6 +55,7 @@ def main():
                     help="9 = Falcon-512 (the headline workload, BASELINE.json configs[2]); 10 = Falcon-1024 (A/B runs only)")
     ap.add_argument("--malformed", type=int, default=0, help="permille of malformed items in the timed corpus (A/B runs only)")
     ap.add_argument("--overlap", type=int, default=-1, help="override FA_OPT_OVERLAP (A/B runs only)")
+    ap.add_argument("--grid-per-cu", type=int, default=-1, help="override FA_OPT_GRID_PER_CU (A/B runs only)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process group for the barrier and the max-over-ranks timing; gloo + --same-gpu rehearses the "
                          "N > 1 path on a one-GPU box")
@@ -92,6 +93,8 @@ def main():
         ctx.set_option(capi.OPT_CHUNK_ITEMS, args.chunk)
     if args.overlap >= 0:
         ctx.set_option(capi.OPT_OVERLAP, args.overlap)
+    if args.grid_per_cu >= 0:
+        ctx.set_option(capi.OPT_GRID_PER_CU, args.grid_per_cu)
 
     # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
     n_items = args.items

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/falcon_amd.h"
@@ -230,6 +231,8 @@ struct fa_ctx {
   DevBuf h_pk, h_sig, h_msg, h_off, h_a, h_b, h_c;
   std::vector<EventPair> events;
   uint32_t retried = 0;
+  uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
+  std::vector<std::pair<const void*, uint32_t>> resident;  // kernel -> workgroups of VERIFY_WG threads resident per CU
 };
 
 namespace {
@@ -267,6 +270,40 @@ int timed(fa_ctx* ctx, hipStream_t s, int kind, F&& launch)
 }
 
 bool aligned4(const void* p) { return ((uintptr_t)p & 3u) == 0; }
+
+// Grid of a grid-stride kernel (one item per wave, VERIFY_WG threads per workgroup) that has `want` workgroups of
+// work. Default: GRID_ROUNDS times what the GPU holds at once. Measured (tools/grid_sweep.sh, 2^20 items): waves do
+// not advance at one rate, so a grid of exactly the resident workgroups ends with most of the GPU waiting for the
+// slowest (Falcon-512 verify kernel 1.74 ms), and so does a small multiple of it (8 per CU: 1.64 ms, the last
+// 3/8 of the items at three waves per SIMD instead of five); with 60-80 per CU (12-16 rounds, 13-17 items per
+// wave) the dispatcher evens that out (1.47 ms), and beyond that the per-workgroup start (twiddle tables into LDS,
+// one item's loads not hidden) costs more than it gains (480 per CU: 1.54 ms; one item per wave: 1.65 ms).
+// Falcon-1024: 3.78 ms at 8 per CU, 3.48-3.52 ms at 24-48 (8-16 rounds).
+constexpr uint32_t GRID_ROUNDS = 12;
+template <typename K>
+uint32_t stride_grid(fa_ctx* ctx, K kernel, uint32_t want)
+{
+  uint32_t per_cu = ctx->grid_per_cu;
+  if (per_cu == 0) {  // resident workgroups per CU of this kernel, asked once
+    const void* key = (const void*)kernel;
+    for (const auto& e : ctx->resident)
+      if (e.first == key) per_cu = e.second;
+    if (per_cu == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, VERIFY_WG, 0) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 8;
+      }
+      per_cu = (uint32_t)nb;
+      try {
+        ctx->resident.emplace_back(key, per_cu);
+      } catch (...) {  // not cached: asked again next time
+      }
+    }
+    per_cu *= GRID_ROUNDS;
+  }
+  return std::max<uint32_t>(1u, std::min<uint32_t>(want, (uint32_t)ctx->num_cu * per_cu));
+}
 
 // FA_WIRE_SPEC: repack `count` specification-format public keys into the reference's form in the context's
 // buffer and return that; FA_WIRE_REFERENCE: the keys as they are.
@@ -387,21 +424,12 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   A.half = ctx->wire == FA_WIRE_SPEC ? Q / 2u + 1u : Q / 2u;
   A.dbg = dbg;
   const uint32_t want = (slots + VERIFY_WAVES - 1) / VERIFY_WAVES;
-  const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * 8u);
-  rc = timed(ctx, s, 2, [&] {
-    if (keys.prepared) {
-      if (debug)
-        hipLaunchKernelGGL((verify_kernel<LOGN, true, true>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
-      else
-        hipLaunchKernelGGL((verify_kernel<LOGN, false, true>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
-    } else {
-      if (debug)
-        hipLaunchKernelGGL((verify_kernel<LOGN, true, false>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
-      else
-        hipLaunchKernelGGL((verify_kernel<LOGN, false, false>), dim3(grid), dim3(VERIFY_WG), 0, s, A);
-    }
-  });
-  return rc;
+  auto launch = [&](auto kernel) {
+    const uint32_t grid = stride_grid(ctx, kernel, want);
+    return timed(ctx, s, 2, [&] { hipLaunchKernelGGL(kernel, dim3(grid), dim3(VERIFY_WG), 0, s, A); });
+  };
+  if (keys.prepared) return debug ? launch(verify_kernel<LOGN, true, true>) : launch(verify_kernel<LOGN, false, true>);
+  return debug ? launch(verify_kernel<LOGN, true, false>) : launch(verify_kernel<LOGN, false, false>);
 }
 
 DebugOut debug_out(const fa_debug* dbgp, bool& debug)
@@ -515,7 +543,7 @@ int hash_to_point_dev(fa_ctx* ctx, size_t count, const uint8_t* salt, const uint
                          idx, slots, nblk, (uint64_t*)ctx->hraw.p);
     });
     if (r) return r;
-    const uint32_t grid = std::min<uint32_t>((slots + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+    const uint32_t grid = stride_grid(ctx, sample_kernel<LOGN>, (slots + VERIFY_WAVES - 1) / VERIFY_WAVES);
     hipLaunchKernelGGL(sample_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, (const uint64_t*)ctx->hraw.p, idx, slots, nblk,
                        item_base, c_, (uint32_t*)ctx->retry_count.p, (uint32_t*)ctx->retry_list.p);
     return (int)hipGetLastError();
@@ -554,7 +582,7 @@ int polymul_dev(fa_ctx* ctx, size_t count, const uint16_t* a, const uint16_t* b,
   constexpr size_t MAXP = 1u << 30;  // the kernel indexes polynomials with 32 bits
   for (size_t p0 = 0; p0 < count; p0 += MAXP) {
     const uint32_t n = (uint32_t)std::min(MAXP, count - p0);
-    const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+    const uint32_t grid = stride_grid(ctx, polymul_kernel<LOGN>, (n + VERIFY_WAVES - 1) / VERIFY_WAVES);
     const size_t o = p0 << LOGN;
     const int rc = timed(ctx, s, 3, [&] {
       hipLaunchKernelGGL(polymul_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, a + o, b + o, c + o, n, ctx->d_tw[T],
@@ -717,6 +745,10 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
       if (value < 0 || value > 64) return FA_E_ARG;
       ctx->host_threads = (uint32_t)value;
       return 0;
+    case FA_OPT_GRID_PER_CU:
+      if (value < 0 || value > 65536) return FA_E_ARG;
+      ctx->grid_per_cu = (uint32_t)value;
+      return 0;
     default:
       return FA_E_ARG;
   }
@@ -798,15 +830,15 @@ int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, 
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
   const int T = logn - 9;
-  const uint32_t n = (uint32_t)nkeys;
-  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  const uint32_t n = (uint32_t)nkeys, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   {
     const int rc = keys_in_reference_form(ctx, logn, s, pk, nkeys, &pk);
     if (rc) return rc;
   }
 #define FA_LAUNCH_PREP(LN, PACKED)                                                                                      \
-  hipLaunchKernelGGL((prepare_keys_kernel<LN, PACKED>), dim3(grid), dim3(VERIFY_WG), 0, s, pk, h, n, prepared,           \
-                     ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
+  hipLaunchKernelGGL((prepare_keys_kernel<LN, PACKED>), dim3(stride_grid(ctx, prepare_keys_kernel<LN, PACKED>, want)),   \
+                     dim3(VERIFY_WG), 0, s, pk, h, n, prepared, ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T],              \
+                     ctx->d_itwc[T], ctx->nc[T])
   if (logn == 9) {
     if (pk) FA_LAUNCH_PREP(9, true); else FA_LAUNCH_PREP(9, false);
   } else {
@@ -1124,14 +1156,13 @@ int fa_compute_public_keys_dev(fa_ctx* ctx, int logn, size_t count, const int32_
   if (gd.err) return gd.err;
   hipStream_t s = (hipStream_t)stream;
   const int T = logn - 9;
-  const uint32_t n = (uint32_t)count;
-  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   if (logn == 9)
-    hipLaunchKernelGGL(pubkey_kernel<9>, dim3(grid), dim3(VERIFY_WG), 0, s, f, g, h, n, ctx->d_tw[T], ctx->d_itw[T],
-                       ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+    hipLaunchKernelGGL(pubkey_kernel<9>, dim3(stride_grid(ctx, pubkey_kernel<9>, want)), dim3(VERIFY_WG), 0, s, f, g, h, n,
+                       ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
   else
-    hipLaunchKernelGGL(pubkey_kernel<10>, dim3(grid), dim3(VERIFY_WG), 0, s, f, g, h, n, ctx->d_tw[T], ctx->d_itw[T],
-                       ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+    hipLaunchKernelGGL(pubkey_kernel<10>, dim3(stride_grid(ctx, pubkey_kernel<10>, want)), dim3(VERIFY_WG), 0, s, f, g, h, n,
+                       ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
   return (int)hipGetLastError();
 }
 
@@ -1170,11 +1201,10 @@ int fa_ntt_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, uint
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
   const int T = logn - 9;
-  const uint32_t n = (uint32_t)count;
-  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
 #define FA_LAUNCH_NTT(LN, INV)                                                                                          \
-  hipLaunchKernelGGL((ntt_kernel<LN, INV>), dim3(grid), dim3(VERIFY_WG), 0, s, a, out, n, ctx->d_tw[T], ctx->d_itw[T],  \
-                     ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
+  hipLaunchKernelGGL((ntt_kernel<LN, INV>), dim3(stride_grid(ctx, ntt_kernel<LN, INV>, want)), dim3(VERIFY_WG), 0, s,   \
+                     a, out, n, ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
   if (logn == 9) {
     if (inverse) FA_LAUNCH_NTT(9, true); else FA_LAUNCH_NTT(9, false);
   } else {
@@ -1215,16 +1245,15 @@ int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, 
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  const uint32_t n = (uint32_t)count;
-  const uint32_t grid = std::min<uint32_t>((n + VERIFY_WAVES - 1) / VERIFY_WAVES, (uint32_t)ctx->num_cu * 8u);
+  const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   {
     const int rc = keys_in_reference_form(ctx, logn, s, pk, count, &pk);
     if (rc) return rc;
   }
   if (logn == 9)
-    hipLaunchKernelGGL(decode_pkeys_kernel<9>, dim3(grid), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
+    hipLaunchKernelGGL(decode_pkeys_kernel<9>, dim3(stride_grid(ctx, decode_pkeys_kernel<9>, want)), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
   else
-    hipLaunchKernelGGL(decode_pkeys_kernel<10>, dim3(grid), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
+    hipLaunchKernelGGL(decode_pkeys_kernel<10>, dim3(stride_grid(ctx, decode_pkeys_kernel<10>, want)), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
   return (int)hipGetLastError();
 }
 
