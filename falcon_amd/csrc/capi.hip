@@ -15,6 +15,30 @@
 #include "verify_kernel.hpp"
 #include "zq.hpp"
 
+namespace fa {
+
+// Small batches (a pass that does not fill the GPU) are bound by the latency of the two lane-per-item kernels --
+// one item: fast decoder 42 us, hash kernel 98 us (Falcon-512) -- which do not depend on each other. This kernel
+// runs both at once, in 64-thread workgroups: the first `nd` workgroups are decoder waves, the rest hash waves.
+// (Two streams do the same but each cross-stream dependency costs about as much as it saves; on a full GPU the
+// pair gains nothing)
+template <int LOGN>
+__global__ __launch_bounds__(64) void front_small_kernel(uint32_t nd, const uint8_t* __restrict__ sig, uint32_t count,
+                                                         uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
+                                                         uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
+                                                         uint32_t* __restrict__ slow_list, uint32_t spec,
+                                                         const uint8_t* __restrict__ msg, const uint64_t* __restrict__ msg_off,
+                                                         uint32_t mlen, uint32_t nblk, uint64_t* __restrict__ hraw)
+{
+  constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  if (blockIdx.x < nd)  // workgroup-uniform
+    decode_fast_body<LOGN>(blockIdx.x, sig, count, s2, sqn, st, slow_count, slow_list, spec);
+  else
+    hash_body<64>(blockIdx.x - nd, sig, SIGLEN, msg, msg_off, mlen, nullptr, count, nblk, hraw);
+}
+
+}  // namespace fa
+
 using namespace fa;
 
 #define HIP_TRY(expr)                      \
@@ -231,6 +255,7 @@ struct fa_ctx {
   DevBuf h_pk, h_sig, h_msg, h_off, h_a, h_b, h_c;
   std::vector<EventPair> events;
   uint32_t retried = 0;
+  uint32_t small_batch = 1u << 15;  // passes of at most this many items run decoder and hash waves in one kernel (front_small_kernel)
   uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
   std::vector<std::pair<const void*, uint32_t>> resident;  // kernel -> workgroups of VERIFY_WG threads resident per CU
 };
@@ -363,6 +388,33 @@ int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig,
   return rc;
 }
 
+// decode_stage and the hash kernel for a small pass: front_small_kernel, then the generic decoder's fix-up pass,
+// all on `s` (no second stream: a cross-stream dependency costs more than the fix-up pass takes).
+template <int LOGN>
+int front_small(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig, const uint8_t* msg, const uint64_t* msg_off,
+                uint32_t mlen, uint32_t nblk)
+{
+  int rc;
+  if ((rc = ctx->slow_count.reserve(4))) return rc;
+  if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
+  uint16_t* d_s2 = (uint16_t*)ctx->s2.p;
+  uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
+  uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
+  uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
+  uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
+  const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC), nd = (slots + 63) / 64;
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
+  rc = timed(ctx, s, 1, [&] {  // booked as hash time: the hash waves are the longer half
+    hipLaunchKernelGGL(front_small_kernel<LOGN>, dim3(2 * nd), dim3(64), 0, s, nd, sig, slots, d_s2, d_sqn, d_st2, d_cnt, d_list,
+                       spec, msg, msg_off, mlen, nblk, (uint64_t*)ctx->hraw.p);
+  });
+  if (rc) return rc;
+  return timed(ctx, s, 0, [&] {
+    hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig,
+                       (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2, spec);
+  });
+}
+
 // One pass of the three kernels over `slots` items. idx == nullptr: slot s is item s of the arrays
 // given (already offset to the chunk); else item idx[s] of the whole arrays.
 template <int LOGN>
@@ -383,22 +435,27 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
   uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
   uint64_t* d_hraw = (uint64_t*)ctx->hraw.p;
+  const bool small = !idx && slots <= ctx->small_batch;  // does not fill the GPU: latency-bound
 
   if (idx) {  // re-hash pass: a handful of items, the generic decoder is enough
     rc = timed(ctx, s, 0, [&] {
       hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
                          slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2, (uint32_t)(ctx->wire == FA_WIRE_SPEC));
     });
+  } else if (small) {
+    rc = front_small<LOGN>(ctx, s, slots, sig, msg, msg_off, mlen, nblk);
   } else {
     rc = decode_stage<LOGN>(ctx, s, slots, sig, ctx->overlap);
   }
   if (rc) return rc;
-  rc = timed(ctx, s, 1, [&] {
-    hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, sig, SIGLEN, msg,
-                       msg_off, mlen, idx, slots, nblk, d_hraw);
-  });
-  if (rc) return rc;
-  if (!idx && ctx->overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  if (!small) {
+    rc = timed(ctx, s, 1, [&] {
+      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, sig, SIGLEN, msg,
+                         msg_off, mlen, idx, slots, nblk, d_hraw);
+    });
+    if (rc) return rc;
+    if (!idx && ctx->overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  }
 
   VerifyArgs<LOGN> A;
   A.pk = keys.pk;
@@ -744,6 +801,10 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
     case FA_OPT_HOST_THREADS:
       if (value < 0 || value > 64) return FA_E_ARG;
       ctx->host_threads = (uint32_t)value;
+      return 0;
+    case FA_OPT_SMALL_BATCH_ITEMS:
+      if (value < 0 || value > (1 << 20)) return FA_E_ARG;
+      ctx->small_batch = (uint32_t)value;
       return 0;
     case FA_OPT_GRID_PER_CU:
       if (value < 0 || value > 65536) return FA_E_ARG;

@@ -235,11 +235,12 @@ constexpr int DF_RING_DW = 33;   // dwords per lane: mirror + 32 ring dwords (od
 constexpr int DF_OUT = 20;       // dwords per lane of the output stage: 16 + 4 (keeps 16-byte alignment, spreads banks)
 constexpr uint32_t DF_AHEAD = 72;  // bytes beyond the cursor a chunk may touch: 64 consumed + one dword pair
 
+// The kernel's body for workgroup (= wave) `block`; also run by front_small_kernel (capi.hip).
 template <int LOGN>
-__global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restrict__ sig, uint32_t count,
-                                                         uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
-                                                         uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
-                                                         uint32_t* __restrict__ slow_list, uint32_t spec)
+__device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* __restrict__ sig, uint32_t count,
+                                                 uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
+                                                 uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
+                                                 uint32_t* __restrict__ slow_list, uint32_t spec)
 {
   constexpr int N = 1 << LOGN;
   constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   __shared__ uint32_t s_ld[64], s_want[64];  // per row: pieces in the ring, pieces wanted
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t slot0 = blockIdx.x * 64u;
+  const uint32_t slot0 = block * 64u;
   const uint32_t slot = slot0 + lane;
   const bool live = slot < count;
   const uint32_t row = live ? slot : count - 1u;  // idle lanes shadow the last row and write nothing
@@ -410,6 +411,15 @@ __global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restri
   }
   st[slot] = failed ? ST_BAD_ENCODING : ST_OK;
   sqn[slot] = norm;
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restrict__ sig, uint32_t count,
+                                                         uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
+                                                         uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
+                                                         uint32_t* __restrict__ slow_list, uint32_t spec)
+{
+  decode_fast_body<LOGN>(blockIdx.x, sig, count, s2, sqn, st, slow_count, slow_list, spec);
 }
 
 // ---- decoding::decode_sig<N> (decoding.hpp:369-391) as a batched operator: the last step ----

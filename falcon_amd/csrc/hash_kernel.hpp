@@ -128,14 +128,16 @@ constexpr int HASH_WG = 256;
 #ifndef FA_HASH_WAVES
 #define FA_HASH_WAVES 3
 #endif
-__global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
-                                                       const uint8_t* __restrict__ msg,
-                                                       const uint64_t* __restrict__ msg_off, uint32_t mlen,
-                                                       const uint32_t* __restrict__ idx, uint32_t count,
-                                                       uint32_t nblk, uint64_t* __restrict__ hraw)
+// The kernel's body for workgroup `block` of WG threads (a template so that front_small_kernel, decode_kernel.hpp's
+// companion for small batches, can run it in 64-thread workgroups beside the decoder).
+template <int WG>
+__device__ __forceinline__ void hash_body(uint32_t block, const uint8_t* __restrict__ sig, uint32_t siglen,
+                                          const uint8_t* __restrict__ msg, const uint64_t* __restrict__ msg_off, uint32_t mlen,
+                                          const uint32_t* __restrict__ idx, uint32_t count, uint32_t nblk,
+                                          uint64_t* __restrict__ hraw)
 {
-  __shared__ uint64_t stage[HASH_WG / 64][64 * 17];
-  const uint32_t slot = blockIdx.x * HASH_WG + threadIdx.x;
+  __shared__ uint64_t stage[WG / 64][64 * 17];
+  const uint32_t slot = block * WG + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const bool live = slot < count;
   const uint32_t item = live ? (idx ? idx[slot] : slot) : 0u;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint
 
   // --- squeeze nblk blocks (hashing.hpp:36-39); wave-uniform trip count ---
   uint64_t* st = stage[wave];
-  const uint32_t slot0 = blockIdx.x * HASH_WG + wave * 64u;  // first slot of this wave
+  const uint32_t slot0 = block * WG + wave * 64u;  // first slot of this wave
   const size_t row_words = (size_t)nblk * 17u;
   for (uint32_t b = 0; b < nblk; b++) {
     keccak_f1600(a);
@@ -207,6 +209,15 @@ __global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+}
+
+__global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
+                                                       const uint8_t* __restrict__ msg,
+                                                       const uint64_t* __restrict__ msg_off, uint32_t mlen,
+                                                       const uint32_t* __restrict__ idx, uint32_t count,
+                                                       uint32_t nblk, uint64_t* __restrict__ hraw)
+{
+  hash_body<HASH_WG>(blockIdx.x, sig, siglen, msg, msg_off, mlen, idx, count, nblk, hraw);
 }
 
 }  // namespace fa

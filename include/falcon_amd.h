@@ -51,6 +51,7 @@ extern "C" {
 #define FA_OPT_HOST_THREADS 7    /* host threads that stage pageable caller memory through pinned buffers, default 6; 0: the runtime's own path */
 
 #define FA_OPT_WIRE_FORMAT 8     /* FA_WIRE_REFERENCE (default) or FA_WIRE_SPEC, see below */
+#define FA_OPT_SMALL_BATCH_ITEMS 10 /* passes of at most this many items run decoder and hash waves in one kernel (latency), default 2^15; 0: never */
 #define FA_OPT_GRID_PER_CU 9     /* workgroups per CU of the one-wave-per-item kernels; 0 (default): 12 x what the GPU holds at once */
 
 /* Wire format of public keys and signatures, for every entry point that parses them (verify, prepare_keys from

@@ -114,6 +114,26 @@ def test_chunked_passes_and_rehash(oracle, corpus, logn):
         c.close()
 
 
+@pytest.mark.parametrize("logn", [9, 10])
+def test_front_end_paths_and_grids(oracle, corpus, logn):
+    """The same batch through both front ends -- decoder and hash waves in one kernel (small passes) and one kernel
+    after the other (full passes) -- and with odd grids of the one-wave-per-item kernels (one workgroup, a
+    prime per CU, more workgroups than items need): identical to the oracle each time."""
+    from falcon_amd import capi
+    pk, msg, sig, _ = corpus.generate(logn, 777, seed=31 + logn, malformed_permille=300)
+    flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
+    c = capi.Context(0)
+    try:
+        for small, grid in ((0, 0), (1 << 20, 0), (0, 1), (1 << 20, 7), (0, 65536)):
+            c.set_option(capi.OPT_SMALL_BATCH_ITEMS, small)
+            c.set_option(capi.OPT_GRID_PER_CU, grid)
+            acc, gdbg = c.verify_many(logn, pk, msg, sig, debug=True)
+            _compare_debug(logn, flags, odbg, acc, gdbg)
+            np.testing.assert_array_equal(c.verify_many(logn, pk, msg, sig), acc)
+    finally:
+        c.close()
+
+
 def test_mixed_batch(ctx, oracle, corpus):
     """fa_verify_mixed: Falcon-512 and Falcon-1024 items interleaved, split by N on the host."""
     rng = np.random.default_rng(3)
