@@ -230,6 +230,14 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __rest
 //   * Output: the 64 x 32 coefficients of a chunk form one contiguous 4 KiB tile (s2_tile_offset); it is
 //     turned through LDS and leaves as four fully coalesced 1 KiB stores.
 // ------------------------------------------------------------------------------------------------
+// s_waitcnt vmcnt(0), stated once on every path. The loads of a refill are consumed under per-lane conditions; left
+// to itself hipcc puts its wait inside each conditional block, so on the path around the block the load still counts
+// as outstanding, and the next refill -- which reuses those registers -- then waits for ALL memory operations before
+// EACH of its loads: the four loads of a refill (and the eight of the prologue) went out one HBM round trip after
+// the other. With the wait in front of the blocks the compiler knows the registers are free and the loads issue
+// back to back.
+__device__ __forceinline__ void vmem_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), expcnt/lgkmcnt untouched
+
 constexpr int DF_CH = 32;        // coefficients per chunk
 constexpr int DF_RING_DW = 33;   // dwords per lane: mirror + 32 ring dwords (odd stride: conflict free)
 constexpr int DF_OUT = 20;       // dwords per lane of the output stage: 16 + 4 (keeps 16-byte alignment, spreads banks)
@@ -285,8 +293,9 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
     for (int t = 0; t < 8; t++) {
       const uint8_t* b = sig + (size_t)min(slot0 + 8u * t + (lane >> 3), count - 1u) * SIGLEN + 41;
       const uint32_t last = ((uint32_t)((uintptr_t)b & 15u) + BODY - 1u) >> 4;
-      if ((lane & 7u) < 6u) v[t] = ((const uint4*)(b - ((uintptr_t)b & 15u)))[min(lane & 7u, last)];
-    }
+      v[t] = ((const uint4*)(b - ((uintptr_t)b & 15u)))[min(lane & 7u, last)];  // lanes 6, 7 of a group load too (and drop it):
+    }                                                                          // unconditional loads issue back to back
+    vmem_wait_all();
 #pragma unroll
     for (int t = 0; t < 8; t++)
       if ((lane & 7u) < 6u) put_piece(ring + (8u * t + (lane >> 3)) * DF_RING_DW, lane & 7u, v[t]);
@@ -356,6 +365,7 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
     }
     // The pieces requested one chunk ago have arrived behind the arithmetic; by now the cursor has moved
     // on by at least 36 bytes, so the at most 8 live pieces [cursor >> 7, want) fit the ring.
+    vmem_wait_all();
 #pragma unroll
     for (int t = 0; t < 4; t++)
       if (lp[t] != ~0u) put_piece(ring + (16u * t + (lane >> 2)) * DF_RING_DW, lp[t], nv[t]);

@@ -584,6 +584,11 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   if (slot >= A.count) return;
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED>(A, slot, lane, cur);
+  // The first item's loads are waited for here, once, before the loop. Without this the loop header inherits
+  // "loads into cur outstanding" from this path, hipcc's wait insertion cannot tell how many loads were issued
+  // since, and every iteration waited for ALL memory operations (s_waitcnt vmcnt(0)) right after issuing the next
+  // item's prefetch -- the prefetch hid nothing.
+  vmem_wait_all();
 
   while (true) {
     const uint32_t nslot = slot + nwaves;
@@ -936,6 +941,7 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
     av[m] = a[(size_t)p * N + idxA<LOGN>(lane, m)];
     bv[m] = b[(size_t)p * N + idxA<LOGN>(lane, m)];
   }
+  vmem_wait_all();  // as in verify_kernel: nothing outstanding at the loop header
   while (true) {
     const uint32_t np = p + nwaves;
     const bool more = np < count;
