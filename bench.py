@@ -161,19 +161,27 @@ def main():
         items_per_launch = n_items * args.steps / max(kern_n[dom], 1)
         avg_ms = kern_ms[dom] / max(kern_n[dom], 1)
         achieved = OPS_512[dom] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic, issued = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                counters = json.load(open(tpath))
+                traffic = counters.get(dom)
+                issued = counters.get("valu_instructions_per_launch", {}).get(dom)
             except Exception:
-                traffic = None
+                traffic, issued = None, None
         result["roofline"] = {
             "bound": "valu", "kernel": dom, "achieved": achieved, "peak": PEAK_VALU_TIOPS, "unit": "Tiop/s",
             "frac": achieved / PEAK_VALU_TIOPS, "traffic": traffic,
             "avg_launch_ms": avg_ms, "items_per_launch": items_per_launch, "algorithmic_ops_per_item": OPS_512[dom],
-            "note": "integer VALU work, no MFMA; peak = 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s (SURVEY.md 8d)",
+            "note": "integer VALU work, no MFMA; peak = 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s (SURVEY.md 8d). achieved counts the "
+                    "reference's operations (11 per butterfly, 4 transforms); the kernel issues 5 per butterfly and runs 3 "
+                    "transforms, so frac can pass 1 -- issue_utilisation is the share of the vector issue slots in use",
         }
+        if issued and avg_ms > 0 and logn == 9 and n_items == 1 << 20 and not args.malformed:
+            # wave instructions of this kernel per launch (PMC, profiles/) x 4 cycles per issue slot / (SIMDs x clock x time)
+            result["roofline"]["issue_utilisation"] = issued * 4 / (1024 * 2.4e9 * avg_ms * 1e-3)
+            result["roofline"]["issued_valu_instructions"] = issued
         result["kernels_ms_per_step"] = {k: v / args.steps for k, v in kern_ms.items()}
         per_gpu_rate = n_items * args.steps / elapsed
         # the same launch against the HBM roofline, in the contract's form: SURVEY.md 8(d)'s compulsory bytes per
