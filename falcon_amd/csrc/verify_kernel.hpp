@@ -510,6 +510,16 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   slot = __builtin_amdgcn_readfirstlane(slot);  // wave-uniform: row bases become scalar, lanes add 32-bit offsets
   r.item = A.idx ? A.idx[slot] : slot;
   r.item = __builtin_amdgcn_readfirstlane(r.item);
+  uint32_t key = 0;
+  if constexpr (PREPARED) {  // the key's index, before the bulk loads: a load that must be waited for in the middle of
+    key = A.key_idx ? A.key_idx[r.item] : A.item_base + r.item;  // them makes every load before it a load waited for
+    key = __builtin_amdgcn_readfirstlane(key);
+  }
+  if constexpr (PREPARED) {
+    const uint32_t* krow = (const uint32_t*)(A.prepared + (size_t)key * G::N);
+#pragma unroll
+    for (int j = 0; j < G::R / 2; j++) r.hk[j] = krow[lane * (G::R / 2) + j];
+  }
   const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
   const uint32_t ndw = A.nblk * 34u;
 #pragma unroll
@@ -537,12 +547,7 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
     for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];
   }
   if constexpr (PREPARED) {
-    uint32_t key = A.key_idx ? A.key_idx[r.item] : A.item_base + r.item;
-    key = __builtin_amdgcn_readfirstlane(key);
-    const uint32_t* krow = (const uint32_t*)(A.prepared + (size_t)key * G::N);
-#pragma unroll
-    for (int j = 0; j < G::R / 2; j++) r.hk[j] = krow[lane * (G::R / 2) + j];
-    r.pal = 0u;
+    r.pal = 0u;  // (the key row was requested first, above)
   } else {
     const uint8_t* pkrow = A.pk + (size_t)r.item * G::PKLEN;
     r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
