@@ -616,21 +616,24 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
     if (status == ST_OK) {
       // ---- rejection sampling (hashing.hpp:38-49): 16-bit big-endian draws in stream order ----
       const uint32_t ndw = A.nblk * 34u;
-      auto sample = [&](uint32_t w) {
+      // `bounded`: the draws so far plus this round's 128 cannot exceed N, so no position needs checking
+      auto sample = [&](uint32_t w, bool bounded = false) {
         const uint32_t t0 = ((w & 0xffu) << 8) | ((w >> 8) & 0xffu);
         const uint32_t t1 = ((w >> 8) & 0xff00u) | (w >> 24);
         const bool a0 = t0 < 61445u, a1 = t1 < 61445u;
         const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
-        const uint32_t p0 = have + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
-                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        // both draws of a lane come after all draws of the lanes below it: one prefix count over each mask, chained
+        const uint32_t p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, have))));
         const uint32_t p1 = p0 + (a0 ? 1u : 0u);
-        if (a0 && p0 < (uint32_t)N) cbuf[p0] = (uint16_t)t0;
-        if (a1 && p1 < (uint32_t)N) cbuf[p1] = (uint16_t)t1;
+        if (a0 && (bounded || p0 < (uint32_t)N)) cbuf[p0] = (uint16_t)t0;
+        if (a1 && (bounded || p1 < (uint32_t)N)) cbuf[p1] = (uint16_t)t1;
         have += __popcll(m0) + __popcll(m1);
       };
 #pragma unroll
-      for (int t = 0; t < G::MAXHW; t++)
-        if (have < (uint32_t)N) sample(cur.hw[t]);
+      for (int t = 0; t < G::MAXHW; t++) {
+        if (have < (uint32_t)N) sample(cur.hw[t], (t + 1) * 128 <= N);
+      }
       if (have < (uint32_t)N && ndw > (uint32_t)G::MAXHW * 64u) {  // re-hash pass with more blocks: not prefetched
         const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
         for (uint32_t base = G::MAXHW * 64u; base < ndw && have < (uint32_t)N; base += 64u) {
