@@ -1134,21 +1134,38 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
     for (size_t i = 0; i < count; i++)
       if (logn[i] == ln) who.push_back(i);
     if (who.empty()) continue;
-    std::vector<uint8_t> gpk(who.size() * pklen), gsig(who.size() * siglen), gmsg, gacc(who.size());
-    std::vector<uint64_t> goff(who.size() + 1, 0);
-    for (size_t k = 0; k < who.size(); k++) {
-      const size_t i = who[k];
-      std::memcpy(&gpk[k * pklen], pk + pk_off[i], pklen);
-      std::memcpy(&gsig[k * siglen], sig + sig_off[i], siglen);
-      const size_t ml = (size_t)(msg_off[i + 1] - msg_off[i]);
-      if (ml) gmsg.insert(gmsg.end(), msg + msg_off[i], msg + msg_off[i] + ml);
-      goff[k + 1] = gmsg.size();
+    const size_t nc = who.size();
+    std::vector<uint64_t> goff(nc + 1, 0);
+    for (size_t k = 0; k < nc; k++) {
+      if (msg_off[who[k] + 1] < msg_off[who[k]]) return FA_E_ARG;
+      goff[k + 1] = goff[k] + (msg_off[who[k] + 1] - msg_off[who[k]]);
     }
-    if (gmsg.empty()) gmsg.push_back(0);
-    const int rc = fa_verify_many(ctx, ln, who.size(), gpk.data(), gmsg.data(), goff.data(), 0, gsig.data(), norm_policy,
+    if (goff[nc] && !msg) return FA_E_ARG;
+    std::vector<uint8_t> gpk(nc * pklen), gsig(nc * siglen), gmsg(std::max<uint64_t>(goff[nc], 1)), gacc(nc);
+    // the class's records, gathered into contiguous arrays by the context's host threads (contiguous ranges of items)
+    auto gather = [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; k++) {
+        const size_t i = who[k];
+        std::memcpy(&gpk[k * pklen], pk + pk_off[i], pklen);
+        std::memcpy(&gsig[k * siglen], sig + sig_off[i], siglen);
+        const size_t ml = (size_t)(goff[k + 1] - goff[k]);
+        if (ml) std::memcpy(&gmsg[goff[k]], msg + msg_off[i], ml);
+      }
+    };
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(ctx->host_threads, nc / 4096));
+    std::vector<std::thread> pool;
+    size_t started = 1;  // the calling thread takes range 0
+    try {
+      for (; started < nt; started++) pool.emplace_back(gather, nc * started / nt, nc * (started + 1) / nt);
+    } catch (...) {  // threads that could not be started: their ranges are done below
+    }
+    gather(0, nc / nt);
+    for (auto& th : pool) th.join();
+    for (size_t t = started; t < nt; t++) gather(nc * t / nt, nc * (t + 1) / nt);
+    const int rc = fa_verify_many(ctx, ln, nc, gpk.data(), gmsg.data(), goff.data(), 0, gsig.data(), norm_policy,
                                   gacc.data(), nullptr);
     if (rc) return rc;
-    for (size_t k = 0; k < who.size(); k++) accept[who[k]] = gacc[k];
+    for (size_t k = 0; k < nc; k++) accept[who[k]] = gacc[k];
   }
   } catch (...) {  // std::bad_alloc of the host-side partition: no exception crosses the C ABI
     return FA_E_INTERNAL;

@@ -134,17 +134,20 @@ def test_front_end_paths_and_grids(oracle, corpus, logn):
         c.close()
 
 
-def test_mixed_batch(ctx, oracle, corpus):
-    """fa_verify_mixed: Falcon-512 and Falcon-1024 items interleaved, split by N on the host."""
+@pytest.mark.parametrize("per_class", [150, 9000])
+def test_mixed_batch(ctx, oracle, corpus, per_class):
+    """fa_verify_mixed: Falcon-512 and Falcon-1024 items interleaved, split by N on the host; the larger
+    case is gathered by several host threads."""
     rng = np.random.default_rng(3)
-    p9 = corpus.generate(9, 150, seed=1, malformed_permille=300)
-    p10 = corpus.generate(10, 150, seed=2, malformed_permille=300)
+    n = per_class
+    p9 = corpus.generate(9, n, seed=1, malformed_permille=300)
+    p10 = corpus.generate(10, n, seed=2, malformed_permille=300)
     want9 = oracle.verify_many(9, *p9[:3], threads=8)[0] & 1
     want10 = oracle.verify_many(10, *p10[:3], threads=8)[0] & 1
-    order = rng.permutation(300)
+    order = rng.permutation(2 * n)
     logn, pk, sig, msg, want = [], [], [], [], []
     for o in order:
-        src, w, ln, i = (p9, want9, 9, o) if o < 150 else (p10, want10, 10, o - 150)
+        src, w, ln, i = (p9, want9, 9, o) if o < n else (p10, want10, 10, o - n)
         logn.append(ln); pk.append(src[0][i]); msg.append(src[1][i]); sig.append(src[2][i]); want.append(w[i])
     cat = lambda xs: (np.concatenate(xs), np.concatenate([[0], np.cumsum([x.size for x in xs])]).astype(np.uint64))
     (pkb, pko), (msgb, msgo), (sigb, sigo) = cat(pk), cat(msg), cat(sig)
