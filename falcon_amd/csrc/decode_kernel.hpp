@@ -385,7 +385,11 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const uint32_t r = 16u * t + (lane >> 2);  // row, piece lane & 3
-        if (slot0 + r < count) tile[64u * t + lane] = *(const uint4*)(outb + r * DF_OUT + (lane & 3u) * 4u);
+        // Non-temporal: the tile is read once, by the verify kernel, after 1 GB of other tiles has gone by -- no point in
+        // keeping it in L2 (decoder -7 %; the same hint on the hash kernel's stores gains nothing, and on the
+        // decoder's loads it loses a third: the 64-byte pieces of a row share 128-byte lines across refills).
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if (slot0 + r < count) __builtin_nontemporal_store(*(const u32x4*)(outb + r * DF_OUT + (lane & 3u) * 4u), (u32x4*)&tile[64u * t + lane]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
