@@ -2,16 +2,20 @@
 // reference's own callers use falcon::verify<N> (tests/test_signing.cpp:28-37,
 // examples/sign_one.cpp:34): called by tests/test_cpp_host.py on the GPU box.
 //
-// usage: host_api_check <logn> <count> <mlen> <pk.bin> <msg.bin> <sig.bin> <ndev>
+// usage: host_api_check <logn> <count> <mlen> <pk.bin> <msg.bin> <sig.bin> <ndev> [<outdir>]
 // prints one line of '0'/'1' accept flags from verify_many<N>, a second line from per-item
 // verify<N> calls on the first min(count, 8) items, a third from the prepared-key form, and a fourth from
-// verify_many_sharded<N>.
+// verify_many_sharded<N>. With <outdir>: the operators of the path through their C++ names -- decode_pkeys<N>,
+// decode_sigs<N>, hash_to_point_many<N> (on the decoded salts), ntt_many<N> / intt_many<N>, prepared_keys<N>::from_decoded
+// -- whose raw outputs go to <outdir>/{h,hok,salt,s2,sok,c,ntt,intt}.bin for the caller to compare; a fifth line holds
+// the accept flags of verify_many<N> over the keys prepared from the decoded polynomials.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <iterator>
+#include <string>
 #include <vector>
 
 #include "falcon_amd.hpp"
@@ -26,8 +30,16 @@ static std::vector<uint8_t> slurp(const char* path)
   return std::vector<uint8_t>(std::istreambuf_iterator<char>(f), {});
 }
 
+template<typename T>
+static void dump(const std::string& dir, const char* name, const std::vector<T>& v)
+{
+  std::ofstream f(dir + "/" + name, std::ios::binary);
+  f.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(T)));
+}
+
 template<size_t N>
-static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<uint8_t>& msg, std::vector<uint8_t>& sig, int ndev)
+static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<uint8_t>& msg, std::vector<uint8_t>& sig, int ndev,
+               const char* outdir)
 {
   if (pk.size() != count * falcon::pkey_len<N>() || sig.size() != count * falcon::sig_len<N>() || msg.size() != count * mlen) {
     std::fprintf(stderr, "file sizes do not match count\n");
@@ -56,21 +68,41 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
   falcon::verify_many_sharded<N>(count, ppk.data(), msg.data(), mlen, nullptr, sig.data(), acc2.data(), ndev);
   for (uint8_t a : acc2) std::putchar('0' + a);
   std::putchar('\n');
+  if (outdir) {
+    std::vector<uint16_t> h(count * N, 0xAAAA), c(count * N), t(count * N), back(count * N);
+    std::vector<int16_t> s2(count * N, 0x5555);
+    std::vector<uint8_t> hok(count, 7), sok(count, 7), salt(count * 40, 0xEE);
+    falcon::decode_pkeys<N>(count, pk.data(), h.data(), hok.data());
+    falcon::decode_sigs<N>(count, sig.data(), salt.data(), s2.data(), sok.data());
+    falcon::hash_to_point_many<N>(count, salt.data(), msg.data(), mlen, nullptr, c.data());
+    falcon::ntt_many<N>(count, h.data(), t.data());
+    falcon::intt_many<N>(count, t.data(), back.data());
+    dump(outdir, "h.bin", h); dump(outdir, "hok.bin", hok); dump(outdir, "salt.bin", salt); dump(outdir, "s2.bin", s2);
+    dump(outdir, "sok.bin", sok); dump(outdir, "c.bin", c); dump(outdir, "ntt.bin", t); dump(outdir, "intt.bin", back);
+    // verification::verify<N, beta2>(h, ...) as its callers use it: keys kept decoded (falcon.hpp:226-229). A key whose
+    // header was wrong decodes to zeros here and is then an ordinary (wrong) key.
+    auto keys = falcon::prepared_keys<N>::from_decoded(count, h.data());
+    std::vector<uint8_t> acc5(count, 7);
+    falcon::verify_many<N>(count, keys, nullptr, msg.data(), mlen, nullptr, sig.data(), acc5.data());
+    for (uint8_t a : acc5) std::putchar('0' + a);
+    std::putchar('\n');
+  }
   return 0;
 }
 
 int main(int argc, char** argv)
 {
-  if (argc != 8) {
-    std::fprintf(stderr, "usage: %s logn count mlen pk.bin msg.bin sig.bin ndev\n", argv[0]);
+  if (argc != 8 && argc != 9) {
+    std::fprintf(stderr, "usage: %s logn count mlen pk.bin msg.bin sig.bin ndev [outdir]\n", argv[0]);
     return 2;
   }
   const int logn = std::atoi(argv[1]);
   const size_t count = std::strtoull(argv[2], nullptr, 10), mlen = std::strtoull(argv[3], nullptr, 10);
   auto pk = slurp(argv[4]), msg = slurp(argv[5]), sig = slurp(argv[6]);
   const int ndev = std::atoi(argv[7]);
+  const char* outdir = argc == 9 ? argv[8] : nullptr;
   try {
-    return logn == 9 ? run<512>(count, mlen, pk, msg, sig, ndev) : run<1024>(count, mlen, pk, msg, sig, ndev);
+    return logn == 9 ? run<512>(count, mlen, pk, msg, sig, ndev, outdir) : run<1024>(count, mlen, pk, msg, sig, ndev, outdir);
   } catch (const falcon::device_error& e) {
     std::fprintf(stderr, "device_error: %s\n", e.what());
     return 3;

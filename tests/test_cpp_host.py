@@ -17,12 +17,39 @@ def test_cpp_verify_and_verify_many(tmp_path, oracle, corpus, logn):
     pk, msg, sig, _ = corpus.generate(logn, count, seed=77 + logn, malformed_permille=350)
     for name, a in (("pk", pk), ("msg", msg), ("sig", sig)):
         np.ascontiguousarray(a).tofile(tmp_path / f"{name}.bin")
+    outdir = tmp_path / "out"
+    outdir.mkdir()
     out = subprocess.run([EXE, str(logn), str(count), "32", str(tmp_path / "pk.bin"), str(tmp_path / "msg.bin"),
-                          str(tmp_path / "sig.bin"), "1"], capture_output=True, text=True, timeout=120)
+                          str(tmp_path / "sig.bin"), "1", str(outdir)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    many, single, prepared, sharded = out.stdout.split("\n")[:4]
+    many, single, prepared, sharded, decoded_keys = out.stdout.split("\n")[:5]
     want = "".join(str(int(f) & 1) for f in oracle.verify_many(logn, pk, msg, sig)[0])
     assert many == want
     assert single == want[:8]
     assert prepared == want
     assert sharded == want
+
+    # the operators of the path through their C++ names, against the oracle's functions item by item
+    n = 1 << logn
+    load = lambda name, dt, shape: np.fromfile(outdir / name, dt).reshape(shape)
+    h, hok = load("h.bin", np.uint16, (count, n)), load("hok.bin", np.uint8, count)
+    salt, s2, sok = load("salt.bin", np.uint8, (count, 40)), load("s2.bin", np.int16, (count, n)), load("sok.bin", np.uint8, count)
+    c, fwd, back = load("c.bin", np.uint16, (count, n)), load("ntt.bin", np.uint16, (count, n)), load("intt.bin", np.uint16, (count, n))
+    zero_key_accepts = []
+    for i in range(count):
+        ok, hh = oracle.decode_pkey(logn, pk[i])
+        assert bool(hok[i]) == ok
+        np.testing.assert_array_equal(h[i], hh)
+        # what the reference leaves untouched stays as the caller initialised it (0xEE salt bytes, 0x5555 coefficients)
+        sk, ss, s2o = oracle.decode_sig(logn, sig[i], salt=np.full(40, 0xEE, np.uint8), s2=np.full(n, 0x5555, np.int32))
+        assert bool(sok[i]) == sk
+        np.testing.assert_array_equal(salt[i], ss)
+        np.testing.assert_array_equal(s2[i].astype(np.int32), s2o)
+        np.testing.assert_array_equal(c[i], oracle.hash_to_point(logn, salt[i], msg[i])[0])
+        np.testing.assert_array_equal(fwd[i], oracle.ntt(h[i], logn))
+        np.testing.assert_array_equal(back[i], h[i] % 12289)
+        zero_key_accepts.append(want[i] if ok else None)
+    # keys prepared from the decoded polynomials: same flags wherever the key's header was right
+    for i, w in enumerate(zero_key_accepts):
+        if w is not None:
+            assert decoded_keys[i] == w, i
