@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <exception>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,6 +89,22 @@ inline fa_ctx* context(int device)
 {
   thread_local context_cache cache;
   return cache.get(device);
+}
+
+// One more context per device, shared by the whole process and used under its mutex: verify_many_sharded's worker
+// threads live for one call, and a per-thread context would be created (twiddle tables, workspace, staging buffers:
+// gigabytes of hipMalloc) and destroyed again on every call. These contexts are kept until the process ends and are
+// deliberately not destroyed from a static destructor, which could run after the HIP runtime has shut down.
+struct shared_context {
+  std::mutex lock;
+  fa_ctx* ctx = nullptr;
+};
+inline shared_context& shared_context_for(int device)
+{
+  constexpr int MAX_DEVICES = 64;
+  static shared_context* const slots = new shared_context[MAX_DEVICES];
+  if (device < 0 || device >= MAX_DEVICES) throw device_error("verify_many_sharded (device index)", FA_E_ARG);
+  return slots[device];
 }
 
 }  // namespace detail
@@ -177,9 +194,17 @@ inline void verify_many_sharded(size_t count, const uint8_t* pkeys, const uint8_
     if (lo >= hi) break;
     workers.emplace_back([=, &errors] {
       try {
+        detail::shared_context& sc = detail::shared_context_for(first_device + g);
+        std::lock_guard<std::mutex> hold(sc.lock);  // a context serves one host thread at a time
+        if (!sc.ctx) {
+          const int rc = fa_ctx_create(first_device + g, &sc.ctx);
+          if (rc) throw device_error("fa_ctx_create", rc);
+        }
         // with msg_off the shard passes the whole message array and its own window of offsets
-        verify_many<N>(hi - lo, pkeys + lo * pkey_len<N>(), msg_off ? msgs : msgs + lo * mlen, mlen,
-                       msg_off ? msg_off + lo : nullptr, sigs + lo * sig_len<N>(), accept + lo, first_device + g, policy);
+        const int rc = fa_verify_many(sc.ctx, detail::logn<N>(), hi - lo, pkeys + lo * pkey_len<N>(),
+                                      msg_off ? msgs : msgs + lo * mlen, msg_off ? msg_off + lo : nullptr, (uint32_t)mlen,
+                                      sigs + lo * sig_len<N>(), (int)policy, accept + lo, nullptr);
+        if (rc) throw device_error("fa_verify_many", rc);
       } catch (...) {
         errors[(size_t)g] = std::current_exception();
       }

@@ -66,6 +66,14 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
   falcon::pinned_buffer<uint8_t> ppk(pk.size());  // keys from pinned memory, the rest pageable
   std::copy(pk.begin(), pk.end(), ppk.data());
   falcon::verify_many_sharded<N>(count, ppk.data(), msg.data(), mlen, nullptr, sig.data(), acc2.data(), ndev);
+  {  // a second call runs on the per-device contexts the first one left behind
+    std::vector<uint8_t> again(count, 7);
+    falcon::verify_many_sharded<N>(count, ppk.data(), msg.data(), mlen, nullptr, sig.data(), again.data(), ndev);
+    if (again != acc2) {
+      std::fprintf(stderr, "verify_many_sharded: second call differs from the first\n");
+      return 4;
+    }
+  }
   for (uint8_t a : acc2) std::putchar('0' + a);
   std::putchar('\n');
   if (outdir) {
