@@ -21,7 +21,8 @@
 // the reference's `bool`, so they throw falcon::device_error.
 //
 // A context (device tables + workspace) is created per (thread, device) on first use, so the
-// functions are safe to call concurrently from any number of threads, as the reference's are.
+// functions are safe to call concurrently from any number of threads, as the reference's are
+// (verify_many_sharded, whose worker threads live for one call, uses one shared context per device).
 #pragma once
 #include <cstddef>
 #include <cstdint>
