@@ -12,7 +12,10 @@ LIB_PATH = os.environ.get("FALCON_AMD_LIB") or os.path.join(_HERE, "libfalcon_am
 
 NORM_EXACT64, NORM_WRAP32 = 0, 1
 ST_OK, ST_BAD_PK_HEADER, ST_BAD_SIG_HEADER, ST_BAD_ENCODING, ST_NORM_TOO_LARGE = range(5)
-OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVERLAP, OPT_HOST_CHUNK_ITEMS, OPT_HOST_THREADS, OPT_WIRE_FORMAT, OPT_GRID_PER_CU, OPT_SMALL_BATCH_ITEMS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVERLAP, OPT_HOST_CHUNK_ITEMS, OPT_HOST_THREADS, OPT_WIRE_FORMAT, OPT_GRID_PER_CU, OPT_SMALL_BATCH_ITEMS, OPT_ASYNC = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+E_ARG, E_LOGN, E_ALIGN, E_INTERNAL, E_UNRESOLVED, E_TOO_MANY = -1, -2, -3, -4, -5, -6
+NOALLOC_MAX_ITEMS = 4096
+MAX_MSG_LEN = 0x7fffff00
 WIRE_REFERENCE, WIRE_SPEC = 0, 1
 
 # every symbol include/falcon_amd.h declares
@@ -21,7 +24,8 @@ EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile",
            "fa_sig_len", "fa_prepared_key_len", "fa_prepare_keys", "fa_prepare_keys_dev", "fa_verify_many_prepared",
            "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev", "fa_compute_public_keys",
            "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister",
-           "fa_ntt_many", "fa_ntt_many_dev", "fa_decode_pkeys", "fa_decode_pkeys_dev", "fa_decode_sigs", "fa_decode_sigs_dev"]
+           "fa_ntt_many", "fa_ntt_many_dev", "fa_decode_pkeys", "fa_decode_pkeys_dev", "fa_decode_sigs", "fa_decode_sigs_dev",
+           "fa_finish", "fa_verify_mixed_dev"]
 
 
 class FaDebug(ctypes.Structure):
@@ -37,7 +41,9 @@ class FaProfile(ctypes.Structure):
 
 
 class FalconAmdError(RuntimeError):
-    pass
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 _lib = None
@@ -63,6 +69,8 @@ def load_library():
     lib.fa_verify_many.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug)]
     lib.fa_verify_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug), vp]
     lib.fa_verify_mixed.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.fa_verify_mixed_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.fa_finish.argtypes = [vp, vp, ctypes.POINTER(u64)]
     lib.fa_polymul_many.argtypes = [vp, i32, sz, vp, vp, vp]
     lib.fa_polymul_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     lib.fa_prepared_key_len.argtypes = [i32]
@@ -98,11 +106,27 @@ def load_library():
 def _check(rc, what):
     if rc != 0:
         msg = load_library().fa_strerror(rc).decode()
-        raise FalconAmdError(f"{what} failed: {msg} (code {rc})")
+        raise FalconAmdError(f"{what} failed: {msg} (code {rc})", rc)
 
 
 def _ptr(a):
     return a.ctypes.data if a is not None else None
+
+
+_DUMMY = np.zeros(8, np.uint8)  # stands in for an empty message array (module-level: its address stays valid)
+
+
+def _check_offsets(off, nbytes, what, rec_len=None):
+    """off: monotone offsets that stay inside an array of nbytes bytes (rec_len: fixed record length per entry,
+    else the last entry is the end of the last record)."""
+    if off.size == 0:
+        return
+    if rec_len is None:
+        if (np.diff(off.astype(np.int64)) < 0).any() or int(off[-1]) > nbytes:
+            raise ValueError(f"{what}: offsets must be non-decreasing and end within the array")
+    else:
+        if (off.astype(np.int64) + np.asarray(rec_len, np.int64) > nbytes).any():
+            raise ValueError(f"{what}: a record extends past the end of the array")
 
 
 class PinnedArray:
@@ -189,7 +213,9 @@ class Context:
                    "s1": np.zeros((count, n), np.int16), "norm_exact": np.zeros(count, np.uint64),
                    "norm_wrap32": np.zeros(count, np.uint32), "status": np.zeros(count, np.uint8)}
             dbg = FaDebug(*[_ptr(out[k]) for k, _ in FaDebug._fields_])
-        mp = _ptr(msg) if msg.size else (None if off is None and mlen == 0 else _ptr(np.zeros(8, np.uint8)))
+        if off is not None:
+            _check_offsets(off, msg.size, "msg_off")
+        mp = _ptr(msg) if msg.size else (None if off is None and mlen == 0 else _ptr(_DUMMY))
         rc = self.lib.fa_verify_many(self.handle, logn, count, _ptr(pk), mp, _ptr(off), mlen, _ptr(sig), norm_policy,
                                      _ptr(accept), ctypes.byref(dbg) if dbg is not None else None)
         _check(rc, "fa_verify_many")
@@ -205,8 +231,9 @@ class Context:
             off = np.ascontiguousarray(msg_off, np.uint64)
             if off.shape != (count + 1,):
                 raise ValueError("msg_off must hold count+1 offsets")
+            _check_offsets(off, msg.size, "msg_off")
             mlen = 0
-        mp = _ptr(msg) if msg.size else (None if off is None and mlen == 0 else _ptr(np.zeros(8, np.uint8)))
+        mp = _ptr(msg) if msg.size else (None if off is None and mlen == 0 else _ptr(_DUMMY))
         return msg, off, mlen, mp
 
     def prepare_keys(self, logn, pk=None, h=None):
@@ -279,8 +306,14 @@ class Context:
         arrs = [np.ascontiguousarray(pk, np.uint8), np.ascontiguousarray(pk_off, np.uint64),
                 np.ascontiguousarray(msg, np.uint8), np.ascontiguousarray(msg_off, np.uint64),
                 np.ascontiguousarray(sig, np.uint8), np.ascontiguousarray(sig_off, np.uint64)]
+        if arrs[1].shape != (count,) or arrs[5].shape != (count,) or arrs[3].shape != (count + 1,):
+            raise ValueError("pk_off / sig_off hold count offsets, msg_off count + 1")
+        n1024 = logn == 10
+        _check_offsets(arrs[1], arrs[0].size, "pk_off", np.where(n1024, 1793, 897))
+        _check_offsets(arrs[5], arrs[4].size, "sig_off", np.where(n1024, 1280, 666))
+        _check_offsets(arrs[3], arrs[2].size, "msg_off")
         if arrs[2].size == 0:
-            arrs[2] = np.zeros(8, np.uint8)
+            arrs[2] = _DUMMY
         accept = np.zeros(count, np.uint8)
         rc = self.lib.fa_verify_mixed(self.handle, count, _ptr(logn), *[_ptr(a) for a in arrs], norm_policy,
                                       _ptr(accept))
@@ -327,6 +360,10 @@ class Context:
             raise ValueError("sig shape does not match logn")
         salt = np.zeros((count, 40), np.uint8) if salt is None else salt
         s2 = np.zeros((count, 1 << logn), np.int16) if s2 is None else s2
+        if salt.dtype != np.uint8 or salt.shape != (count, 40) or not salt.flags.c_contiguous:
+            raise ValueError("salt must be a contiguous (count, 40) uint8 array")
+        if s2.dtype != np.int16 or s2.shape != (count, 1 << logn) or not s2.flags.c_contiguous:
+            raise ValueError("s2 must be a contiguous (count, n) int16 array")
         ok = np.zeros(count, np.uint8)
         _check(self.lib.fa_decode_sigs(self.handle, logn, count, _ptr(sig), _ptr(salt), _ptr(s2), _ptr(ok)), "fa_decode_sigs")
         return salt, s2, ok
@@ -341,6 +378,21 @@ class Context:
                                          norm_policy, accept_ptr, ctypes.byref(dbg) if dbg is not None else None,
                                          stream or None)
         _check(rc, "fa_verify_many_dev")
+
+    def verify_mixed_dev(self, count, logn_ptr, pk_ptr, pk_off_ptr, msg_ptr, msg_off_ptr, sig_ptr, sig_off_ptr, accept_ptr,
+                         norm_policy=NORM_EXACT64, stream=0):
+        rc = self.lib.fa_verify_mixed_dev(self.handle, count, logn_ptr, pk_ptr, pk_off_ptr, msg_ptr, msg_off_ptr, sig_ptr,
+                                          sig_off_ptr, norm_policy, accept_ptr, stream or None)
+        _check(rc, "fa_verify_mixed_dev")
+
+    def finish(self, stream=0):
+        """fa_finish: synchronise `stream`; returns the number of unresolved items of the asynchronous calls since
+        the last finish (0 in practice)."""
+        n = ctypes.c_uint64(0)
+        rc = self.lib.fa_finish(self.handle, stream or None, ctypes.byref(n))
+        if rc not in (0, E_UNRESOLVED):
+            _check(rc, "fa_finish")
+        return int(n.value)
 
     def prepare_keys_dev(self, logn, nkeys, pk_ptr, h_ptr, prepared_ptr, stream=0):
         _check(self.lib.fa_prepare_keys_dev(self.handle, logn, nkeys, pk_ptr, h_ptr, prepared_ptr, stream or None),

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <utility>
@@ -23,18 +24,124 @@ namespace fa {
 // (Two streams do the same but each cross-stream dependency costs about as much as it saves; on a full GPU the
 // pair gains nothing)
 template <int LOGN>
-__global__ __launch_bounds__(64) void front_small_kernel(uint32_t nd, const uint8_t* __restrict__ sig, uint32_t count,
+__global__ __launch_bounds__(64) void front_small_kernel(uint32_t nd, const Rows sig, const uint32_t* __restrict__ idx, uint32_t count,
+                                                         const uint32_t* __restrict__ dcount,
                                                          uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
                                                          uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
                                                          uint32_t* __restrict__ slow_list, uint32_t spec,
                                                          const uint8_t* __restrict__ msg, const uint64_t* __restrict__ msg_off,
                                                          uint32_t mlen, uint32_t nblk, uint64_t* __restrict__ hraw)
 {
-  constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
   if (blockIdx.x < nd)  // workgroup-uniform
-    decode_fast_body<LOGN>(blockIdx.x, sig, count, s2, sqn, st, slow_count, slow_list, spec);
+    decode_fast_body<LOGN>(blockIdx.x, sig, idx, count, dcount, s2, sqn, st, slow_count, slow_list, spec);
   else
-    hash_body<64>(blockIdx.x - nd, sig, SIGLEN, msg, msg_off, mlen, nullptr, count, nblk, hraw);
+    hash_body<64>(blockIdx.x - nd, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
+}
+
+// ---- mixed batches (fa_verify_mixed_dev): order-preserving split of the item indices by N ----
+// logn[i] in {9, 10}. Pass 1 counts the Falcon-512 items of every run of PART_ITEMS items, pass 2 (one
+// workgroup) turns the counts into exclusive prefix sums and leaves the totals, pass 3 writes the item
+// indices: class 9 to list[0, n9), class 10 to list[n9, count), each in ascending order (so a pass over a
+// class list walks the records in memory order).
+constexpr uint32_t PART_WG = 256, PART_ITEMS = 1024;
+
+__global__ __launch_bounds__(PART_WG) void partition_count_kernel(const uint8_t* __restrict__ logn, uint32_t count,
+                                                                  uint32_t* __restrict__ run_n9, uint32_t* __restrict__ totals)
+{
+  __shared__ uint32_t s_n9, s_bad;
+  if (threadIdx.x == 0) s_n9 = s_bad = 0u;
+  __syncthreads();
+  uint32_t n9 = 0, bad = 0;
+  for (uint32_t r = 0; r < PART_ITEMS / PART_WG; r++) {
+    const uint32_t i = blockIdx.x * PART_ITEMS + r * PART_WG + threadIdx.x;
+    if (i < count) {
+      const uint32_t t = logn[i];
+      n9 += t == 9u;
+      bad += t != 9u && t != 10u;
+    }
+  }
+  if (n9) atomicAdd(&s_n9, n9);
+  if (bad) atomicAdd(&s_bad, bad);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    run_n9[blockIdx.x] = s_n9;
+    if (s_bad) atomicAdd(&totals[1], s_bad);
+  }
+}
+
+__global__ __launch_bounds__(PART_WG) void partition_scan_kernel(uint32_t* __restrict__ run_n9, uint32_t nruns,
+                                                                 uint32_t* __restrict__ totals)
+{
+  __shared__ uint32_t s_part[PART_WG];
+  // thread t owns the contiguous range of runs [t * per, (t + 1) * per)
+  const uint32_t per = (nruns + PART_WG - 1) / PART_WG;
+  const uint32_t lo = min(threadIdx.x * per, nruns), hi = min(lo + per, nruns);
+  uint32_t sum = 0;
+  for (uint32_t r = lo; r < hi; r++) sum += run_n9[r];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < PART_WG; t++) {
+      const uint32_t v = s_part[t];
+      s_part[t] = acc;
+      acc += v;
+    }
+    totals[0] = acc;  // n9
+  }
+  __syncthreads();
+  uint32_t acc = s_part[threadIdx.x];
+  for (uint32_t r = lo; r < hi; r++) {
+    const uint32_t v = run_n9[r];
+    run_n9[r] = acc;
+    acc += v;
+  }
+}
+
+__global__ __launch_bounds__(PART_WG) void partition_write_kernel(const uint8_t* __restrict__ logn, uint32_t count,
+                                                                  const uint32_t* __restrict__ run_n9,
+                                                                  const uint32_t* __restrict__ totals,
+                                                                  uint32_t* __restrict__ list)
+{
+  __shared__ uint32_t s_wave9[PART_WG / 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t base9 = run_n9[blockIdx.x];                                   // class-9 items before this run
+  uint32_t base10 = totals[0] + (blockIdx.x * PART_ITEMS - base9);       // class-10 items go behind all class-9 ones
+  for (uint32_t r = 0; r < PART_ITEMS / PART_WG; r++) {
+    const uint32_t i = blockIdx.x * PART_ITEMS + r * PART_WG + threadIdx.x;
+    const bool in = i < count;
+    const bool is9 = in && logn[i] == 9u;
+    const unsigned long long m9 = __ballot(is9), min_ = __ballot(in);
+    if (lane == 0) s_wave9[wave] = (uint32_t)__popcll(m9);
+    __syncthreads();
+    uint32_t before9 = 0, round9 = 0;
+    for (uint32_t w = 0; w < PART_WG / 64; w++) {
+      if (w < wave) before9 += s_wave9[w];
+      round9 += s_wave9[w];
+    }
+    const uint32_t r9 = before9 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m9 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m9, 0u));
+    const uint32_t rin = wave * 64u + __builtin_amdgcn_mbcnt_hi((uint32_t)(min_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)min_, 0u));
+    if (in) {
+      if (is9) list[base9 + r9] = i;
+      else list[base10 + (rin - r9)] = i;
+    }
+    const uint32_t live = min(PART_WG, count > blockIdx.x * PART_ITEMS + r * PART_WG ? count - (blockIdx.x * PART_ITEMS + r * PART_WG) : 0u);
+    base9 += round9;
+    base10 += live - round9;
+    __syncthreads();
+  }
+}
+
+// End of the device-side retry pass (asynchronous and allocation-free entry points): this call's number of items
+// that could not be settled on the device -- those beyond the retry pass's capacity plus those that ran out of
+// blocks a second time -- is left in ctl[CTL_UNRESOLVED] and added to the context's running total.
+__global__ void retry_account_kernel(uint32_t* __restrict__ ctl, uint32_t tail_cap, uint32_t* __restrict__ total)
+{
+  uint32_t u = ctl[2];
+  const uint32_t r = ctl[0];
+  if (r > tail_cap) u += r - tail_cap;
+  ctl[2] = u;
+  if (total && u) atomicAdd(total, u);
 }
 
 }  // namespace fa
@@ -212,9 +319,22 @@ int h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t xs, Pi
 }
 
 struct KeySrc {  // where a pass takes its public keys from
-  const uint8_t* pk = nullptr;         // packed keys, one per item
+  Rows pk{ nullptr, nullptr, 0 };      // packed keys, one per item
   const uint16_t* prepared = nullptr;  // or prepared keys (prepare_keys_kernel) ...
   const uint32_t* key_idx = nullptr;   // ... indexed per item (nullable: key = item)
+};
+
+// The caller's arrays of one verify call (device pointers).
+struct Batch {
+  KeySrc keys;
+  Rows sig{ nullptr, nullptr, 0 };
+  const uint8_t* msg = nullptr;
+  const uint64_t* msg_off = nullptr;
+  uint32_t mlen = 0;
+  int policy = FA_NORM_EXACT64;
+  uint8_t* accept = nullptr;
+  DebugOut dbg{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  bool debug = false;
 };
 
 struct EventPair {
@@ -222,7 +342,28 @@ struct EventPair {
   int kind;  // 0 decode, 1 hash, 2 verify, 3 polymul
 };
 
+// Device memory of the pipeline, either the context's own buffers (grown on demand) or a
+// carve-up of the library's static scratch array (fa_verify_many_dev_noalloc).
+enum { CTL_RETRY = 0, CTL_SLOW_UNUSED = 1, CTL_UNRESOLVED = 2, CTL_WORDS = 64 };
+struct Workspace {
+  uint64_t* hraw = nullptr;  // squeezed SHAKE256 blocks
+  size_t hraw_bytes = 0;
+  uint16_t* s2 = nullptr;    // tiled, cap_slots rows
+  uint32_t* sqn = nullptr;
+  uint8_t* st2 = nullptr;
+  uint32_t cap_slots = 0;
+  uint32_t* ctl = nullptr;         // CTL_WORDS counters (256 bytes), zeroed once per call: [CTL_RETRY], [CTL_UNRESOLVED]
+  uint32_t* slow_count = nullptr;  // its own 256-byte block, zeroed before every fast-decoder launch
+  uint32_t* retry_list = nullptr;  // items whose hash needs more blocks; as many entries as the call has items
+  uint32_t* slow_list = nullptr;   // cap_slots entries
+  uint32_t* retry2_list = nullptr; // items that failed the device-side retry pass too; tail_cap() entries
+  // slots the device-side retry pass (twice the blocks per item, in the same hraw buffer) can take
+  uint32_t tail_cap() const { return std::min<uint32_t>(cap_slots / 2u, 4096u); }
+};
+
 }  // namespace
+
+constexpr int FA_MAX_DEVICES = 64;
 
 struct fa_ctx {
   int device = 0;
@@ -232,10 +373,13 @@ struct fa_ctx {
   hipStream_t copy = nullptr;    // host-buffer entry points: H2D staging of the next sub-batch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_ready[2] = { nullptr, nullptr };  // staging set k is filled
+  hipEvent_t ev_ws = nullptr;    // recorded behind the last kernel that touches the workspace; every entry point waits for it first
+  bool ws_busy = false;          // ev_ws has been recorded at least once
   uint32_t host_chunk = 1u << 17;  // items per sub-batch of the host-buffer pipeline
   int wire = FA_WIRE_REFERENCE;    // wire format of keys and signatures (FA_OPT_WIRE_FORMAT)
   DevBuf spec_pk;                  // FA_WIRE_SPEC: the batch's keys repacked into the reference's form
   bool overlap = true;
+  bool async = false;              // FA_OPT_ASYNC: device-resident verify calls return without synchronising
   Tw* d_tw[2] = { nullptr, nullptr };
   Tw* d_itw[2] = { nullptr, nullptr };
   Tw* d_twc[2] = { nullptr, nullptr };
@@ -244,20 +388,28 @@ struct fa_ctx {
   uint32_t chunk = 1u << 20;
   uint32_t hash_blocks[2] = { 9, 17 };
   bool profile = false;
+  bool quiet = false;  // inside an allocation-free call: no profiling events, nothing that allocates
   // pipeline workspace (per chunk)
-  DevBuf hraw, s2, sqn, st2, retry_count, retry_list, slow_count, slow_list;
+  DevBuf hraw, s2, sqn, st2, ctl, retry_list, slow_list, retry2_list;
+  DevBuf part_list, part_runs;  // mixed batches: the item indices split by N, per-run counts + totals
+  uint32_t* d_unresolved = nullptr;  // running total of unresolved items of asynchronous calls (256-byte block)
+  uint32_t* h_word = nullptr;        // pinned host words for small device-to-host reads
   // staging for the host-buffer entry points; the verify pipeline double-buffers its per-item inputs
   struct HostStage {
     DevBuf pk, sig, msg, off, kidx, accept, dbg[6];
     PinBuf pin_pk, pin_sig, pin_msg;  // pinned staging for pageable caller memory
   } hs[2];
   uint32_t host_threads = 6;  // host threads staging pageable memory (0: leave it to the runtime)
-  DevBuf h_pk, h_sig, h_msg, h_off, h_a, h_b, h_c;
+  DevBuf h_pk, h_sig, h_msg, h_off, h_a, h_b, h_c, h_off2, h_off3, h_tag;
   std::vector<EventPair> events;
+  std::vector<hipEvent_t> ev_free;  // events ready for reuse (no hipEventCreate inside a timed loop)
   uint32_t retried = 0;
   uint32_t small_batch = 1u << 15;  // passes of at most this many items run decoder and hash waves in one kernel (front_small_kernel)
   uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
-  std::vector<std::pair<const void*, uint32_t>> resident;  // kernel -> workgroups of VERIFY_WG threads resident per CU
+  struct Resident {
+    const void* kernel;
+    uint32_t per_cu;
+  } resident[32] = {};  // kernel -> workgroups of VERIFY_WG threads resident per CU (asked once per kernel)
 };
 
 namespace {
@@ -276,25 +428,64 @@ struct Guard {  // set the context's device for the duration of a call
   }
 };
 
+// Launches `launch` on `s`; with FA_OPT_PROFILE it is bracketed by two HIP events (taken from the context's pool,
+// so a timed loop creates none after its first pass) whose elapsed time fa_get_profile adds up per kind.
 template <typename F>
 int timed(fa_ctx* ctx, hipStream_t s, int kind, F&& launch)
 {
-  if (!ctx->profile) {
+  if (!ctx->profile || ctx->quiet) {
     launch();
     return (int)hipGetLastError();
   }
   EventPair ev{ nullptr, nullptr, kind };
-  HIP_TRY(hipEventCreate(&ev.a));
-  HIP_TRY(hipEventCreate(&ev.b));
-  HIP_TRY(hipEventRecord(ev.a, s));
+  auto take = [&](hipEvent_t* e) -> int {
+    if (!ctx->ev_free.empty()) {
+      *e = ctx->ev_free.back();
+      ctx->ev_free.pop_back();
+      return 0;
+    }
+    return (int)hipEventCreate(e);
+  };
+  auto drop = [&]() {
+    if (ev.a) (void)hipEventDestroy(ev.a);
+    if (ev.b) (void)hipEventDestroy(ev.b);
+  };
+  int rc = take(&ev.a);
+  if (!rc) rc = take(&ev.b);
+  if (!rc) rc = (int)hipEventRecord(ev.a, s);
+  if (rc) {
+    drop();
+    return rc;
+  }
   launch();
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.b, s));
-  ctx->events.push_back(ev);
-  return 0;
+  rc = (int)hipGetLastError();
+  if (!rc) rc = (int)hipEventRecord(ev.b, s);
+  if (!rc) try {
+      ctx->events.push_back(ev);
+      return 0;
+    } catch (...) {
+      rc = FA_E_INTERNAL;
+    }
+  drop();
+  return rc;
 }
 
 bool aligned4(const void* p) { return ((uintptr_t)p & 3u) == 0; }
+
+// Every device-side entry point that uses the context's workspace (or the static scratch array) brackets its work
+// with these: the workspace is one set of buffers, so a call enqueued on stream B must not start overwriting it
+// while the kernels of an earlier call on stream A still read it.
+int ws_begin(fa_ctx* ctx, hipStream_t s)
+{
+  if (ctx->ws_busy) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_ws, 0));
+  return 0;
+}
+int ws_end(fa_ctx* ctx, hipStream_t s)
+{
+  HIP_TRY(hipEventRecord(ctx->ev_ws, s));
+  ctx->ws_busy = true;
+  return 0;
+}
 
 // Grid of a grid-stride kernel (one item per wave, VERIFY_WG threads per workgroup) that has `want` workgroups of
 // work. Default: GRID_ROUNDS times what the GPU holds at once. Measured (tools/grid_sweep.sh, 2^20 items): waves do
@@ -311,8 +502,11 @@ uint32_t stride_grid(fa_ctx* ctx, K kernel, uint32_t want)
   uint32_t per_cu = ctx->grid_per_cu;
   if (per_cu == 0) {  // resident workgroups per CU of this kernel, asked once
     const void* key = (const void*)kernel;
-    for (const auto& e : ctx->resident)
-      if (e.first == key) per_cu = e.second;
+    fa_ctx::Resident* free_slot = nullptr;
+    for (auto& e : ctx->resident) {
+      if (e.kernel == key) per_cu = e.per_cu;
+      if (!e.kernel && !free_slot) free_slot = &e;
+    }
     if (per_cu == 0) {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, VERIFY_WG, 0) != hipSuccess || nb < 1) {
@@ -320,10 +514,7 @@ uint32_t stride_grid(fa_ctx* ctx, K kernel, uint32_t want)
         nb = 8;
       }
       per_cu = (uint32_t)nb;
-      try {
-        ctx->resident.emplace_back(key, per_cu);
-      } catch (...) {  // not cached: asked again next time
-      }
+      if (free_slot) *free_slot = fa_ctx::Resident{ key, per_cu };  // table full: asked again next time
     }
     per_cu *= GRID_ROUNDS;
   }
@@ -350,28 +541,51 @@ int keys_in_reference_form(fa_ctx* ctx, int logn, hipStream_t s, const uint8_t* 
   return 0;
 }
 
-// The signature decoders over `slots` consecutive rows of `sig`, into the context's workspace (s2 tiled,
-// sqn, st2): the fast decoder, then the generic one on the items it queued (those that met the k >= 8 rule).
+constexpr size_t align256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+
+// The context's own workspace for passes of up to `slots` items with `nblk` blocks per item, in a call of `items`
+// items. Buffers only ever grow.
+template <int LOGN>
+int ws_from_ctx(fa_ctx* ctx, uint32_t slots, uint32_t nblk, size_t items, Workspace& ws)
+{
+  const uint32_t cap = std::max<uint32_t>(slots, 128u);  // room for a retry pass of at least 64 items
+  int rc;
+  if ((rc = ctx->hraw.reserve((size_t)cap * nblk * 136))) return rc;
+  if ((rc = ctx->s2.reserve(s2_tile_elems<LOGN>(cap) * 2))) return rc;
+  if ((rc = ctx->sqn.reserve((size_t)cap * 4))) return rc;
+  if ((rc = ctx->st2.reserve((size_t)cap))) return rc;
+  if ((rc = ctx->ctl.reserve(512))) return rc;
+  if ((rc = ctx->retry_list.reserve(std::max<size_t>(items, 1) * 4))) return rc;
+  if ((rc = ctx->slow_list.reserve((size_t)cap * 4))) return rc;
+  if ((rc = ctx->retry2_list.reserve(4096 * 4))) return rc;
+  ws.hraw = (uint64_t*)ctx->hraw.p;
+  ws.hraw_bytes = ctx->hraw.cap;
+  ws.s2 = (uint16_t*)ctx->s2.p;
+  ws.sqn = (uint32_t*)ctx->sqn.p;
+  ws.st2 = (uint8_t*)ctx->st2.p;
+  // the buffers may be larger than asked (an earlier, larger call): the capacity is what all of them hold
+  ws.cap_slots = (uint32_t)std::min<size_t>({ ctx->hraw.cap / ((size_t)nblk * 136), ctx->s2.cap / ((size_t)2 << LOGN) / 64 * 64,
+                                               ctx->sqn.cap / 4, ctx->st2.cap, ctx->slow_list.cap / 4, (size_t)1 << 30 });
+  ws.ctl = (uint32_t*)ctx->ctl.p;
+  ws.slow_count = ws.ctl + CTL_WORDS;
+  ws.retry_list = (uint32_t*)ctx->retry_list.p;
+  ws.slow_list = (uint32_t*)ctx->slow_list.p;
+  ws.retry2_list = (uint32_t*)ctx->retry2_list.p;
+  return 0;
+}
+
+// The signature decoders over `slots` workspace slots, into the workspace (s2 tiled, sqn, st2): the fast
+// decoder, then the generic one on the items it queued (those that met the k >= 8 rule).
 // The fix-up pass is one lane per queued item, a few hundred latency-bound waves at most; with `fork` it runs
 // on the context's second stream and the caller joins (hipStreamWaitEvent(s, ctx->ev_join)) before reading.
 template <int LOGN>
-int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig, bool fork)
+int decode_stage(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, const Rows& sig, const uint32_t* idx, bool fork)
 {
-  int rc;
-  if ((rc = ctx->s2.reserve(s2_tile_elems<LOGN>(slots) * 2))) return rc;
-  if ((rc = ctx->sqn.reserve((size_t)slots * 4))) return rc;
-  if ((rc = ctx->st2.reserve((size_t)slots))) return rc;
-  if ((rc = ctx->slow_count.reserve(4))) return rc;
-  if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
-  uint16_t* d_s2 = (uint16_t*)ctx->s2.p;
-  uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
-  uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
-  uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
-  uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
-  rc = timed(ctx, s, 0, [&] {
-    hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, slots, d_s2, d_sqn,
-                       d_st2, d_cnt, d_list, (uint32_t)(ctx->wire == FA_WIRE_SPEC));
+  const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC);
+  HIP_TRY(hipMemsetAsync(ws.slow_count, 0, 256, s));
+  int rc = timed(ctx, s, 0, [&] {
+    hipLaunchKernelGGL(decode_fast_kernel<LOGN>, dim3((slots + 63) / 64), dim3(64), 0, s, sig, idx, slots, (const uint32_t*)nullptr,
+                       ws.s2, ws.sqn, ws.st2, ws.slow_count, ws.slow_list, spec);
   });
   if (rc) return rc;
   hipStream_t ds = fork ? ctx->aux : s;
@@ -381,8 +595,7 @@ int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig,
   }
   rc = timed(ctx, ds, 0, [&] {
     hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, ds, sig,
-                       (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2,
-                       (uint32_t)(ctx->wire == FA_WIRE_SPEC));
+                       (const uint32_t*)ws.slow_list, idx, slots, (const uint32_t*)ws.slow_count, ws.s2, ws.sqn, ws.st2, spec);
   });
   if (!rc && fork) rc = (int)hipEventRecord(ctx->ev_join, ds);
   return rc;
@@ -391,80 +604,64 @@ int decode_stage(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig,
 // decode_stage and the hash kernel for a small pass: front_small_kernel, then the generic decoder's fix-up pass,
 // all on `s` (no second stream: a cross-stream dependency costs more than the fix-up pass takes).
 template <int LOGN>
-int front_small(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint8_t* sig, const uint8_t* msg, const uint64_t* msg_off,
-                uint32_t mlen, uint32_t nblk)
+int front_small(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, const uint32_t* idx, const Batch& B, uint32_t nblk)
 {
-  int rc;
-  if ((rc = ctx->slow_count.reserve(4))) return rc;
-  if ((rc = ctx->slow_list.reserve((size_t)slots * 4))) return rc;
-  uint16_t* d_s2 = (uint16_t*)ctx->s2.p;
-  uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
-  uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
-  uint32_t* d_cnt = (uint32_t*)ctx->slow_count.p;
-  uint32_t* d_list = (uint32_t*)ctx->slow_list.p;
   const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC), nd = (slots + 63) / 64;
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
-  rc = timed(ctx, s, 1, [&] {  // booked as hash time: the hash waves are the longer half
-    hipLaunchKernelGGL(front_small_kernel<LOGN>, dim3(2 * nd), dim3(64), 0, s, nd, sig, slots, d_s2, d_sqn, d_st2, d_cnt, d_list,
-                       spec, msg, msg_off, mlen, nblk, (uint64_t*)ctx->hraw.p);
+  HIP_TRY(hipMemsetAsync(ws.slow_count, 0, 256, s));
+  int rc = timed(ctx, s, 1, [&] {  // booked as hash time: the hash waves are the longer half
+    hipLaunchKernelGGL(front_small_kernel<LOGN>, dim3(2 * nd), dim3(64), 0, s, nd, B.sig, idx, slots, (const uint32_t*)nullptr, ws.s2,
+                       ws.sqn, ws.st2, ws.slow_count, ws.slow_list, spec, B.msg, B.msg_off, B.mlen, nblk, ws.hraw);
   });
   if (rc) return rc;
   return timed(ctx, s, 0, [&] {
-    hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig,
-                       (const uint32_t*)d_list, slots, (const uint32_t*)d_cnt, true, d_s2, d_sqn, d_st2, spec);
+    hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, B.sig,
+                       (const uint32_t*)ws.slow_list, idx, slots, (const uint32_t*)ws.slow_count, ws.s2, ws.sqn, ws.st2, spec);
   });
 }
 
-// One pass of the three kernels over `slots` items. idx == nullptr: slot s is item s of the arrays
-// given (already offset to the chunk); else item idx[s] of the whole arrays.
+// One pass of the three kernels over `slots` workspace slots. idx == nullptr: slot s is item s of the arrays in
+// B (already offset to the chunk); else item idx[s] of B's arrays. dcount (nullable): device-side number of
+// slots, at most `slots`. retry: a pass over queued items (host loop or device-side retry pass): the generic
+// decoder is enough. Items that run out of blocks are appended to retry_list / *retry_count.
 template <int LOGN>
-int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, const KeySrc& keys, const uint8_t* msg,
-             const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, uint32_t nblk, int policy, uint8_t* accept,
-             const DebugOut& dbg, bool debug, uint32_t item_base)
+int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, const uint32_t* idx, const uint32_t* dcount,
+             bool retry, const Batch& B, uint32_t nblk, uint32_t item_base, uint32_t* retry_count, uint32_t* retry_list)
 {
   constexpr int T = LOGN - 9;
-  constexpr uint32_t SIGLEN = LOGN == 9 ? 666 : 1280;
   if (slots == 0) return 0;
-  int rc = ctx->hraw.reserve((size_t)slots * nblk * 136);
-  if (rc) return rc;
-  if ((rc = ctx->s2.reserve(s2_tile_elems<LOGN>(slots) * 2))) return rc;
-  if ((rc = ctx->sqn.reserve((size_t)slots * 4))) return rc;
-  if ((rc = ctx->st2.reserve((size_t)slots))) return rc;
-
-  uint16_t* d_s2 = (uint16_t*)ctx->s2.p;
-  uint32_t* d_sqn = (uint32_t*)ctx->sqn.p;
-  uint8_t* d_st2 = (uint8_t*)ctx->st2.p;
-  uint64_t* d_hraw = (uint64_t*)ctx->hraw.p;
-  const bool small = !idx && slots <= ctx->small_batch;  // does not fill the GPU: latency-bound
-
-  if (idx) {  // re-hash pass: a handful of items, the generic decoder is enough
+  if (slots > ws.cap_slots || (size_t)slots * nblk * 136 > ws.hraw_bytes) return FA_E_INTERNAL;
+  const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC);
+  const bool small = !retry && slots <= ctx->small_batch;  // does not fill the GPU: latency-bound
+  const bool fork = ctx->overlap && !ctx->quiet;
+  int rc;
+  if (retry) {
     rc = timed(ctx, s, 0, [&] {
-      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, sig, idx,
-                         slots, (const uint32_t*)nullptr, false, d_s2, d_sqn, d_st2, (uint32_t)(ctx->wire == FA_WIRE_SPEC));
+      hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, B.sig,
+                         (const uint32_t*)nullptr, idx, slots, dcount, ws.s2, ws.sqn, ws.st2, spec);
     });
   } else if (small) {
-    rc = front_small<LOGN>(ctx, s, slots, sig, msg, msg_off, mlen, nblk);
+    rc = front_small<LOGN>(ctx, ws, s, slots, idx, B, nblk);
   } else {
-    rc = decode_stage<LOGN>(ctx, s, slots, sig, ctx->overlap);
+    rc = decode_stage<LOGN>(ctx, ws, s, slots, B.sig, idx, fork);
   }
   if (rc) return rc;
   if (!small) {
     rc = timed(ctx, s, 1, [&] {
-      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, sig, SIGLEN, msg,
-                         msg_off, mlen, idx, slots, nblk, d_hraw);
+      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, B.sig, B.msg, B.msg_off, B.mlen,
+                         idx, slots, dcount, nblk, ws.hraw);
     });
     if (rc) return rc;
-    if (!idx && ctx->overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    if (!retry && fork) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
 
   VerifyArgs<LOGN> A;
-  A.pk = keys.pk;
-  A.prepared = keys.prepared;
-  A.key_idx = keys.key_idx;
-  A.hraw = d_hraw;
-  A.s2 = d_s2;
-  A.sqn = d_sqn;
-  A.st2 = d_st2;
+  A.pk = B.keys.pk;
+  A.prepared = B.keys.prepared;
+  A.key_idx = B.keys.key_idx;
+  A.hraw = ws.hraw;
+  A.s2 = ws.s2;
+  A.sqn = ws.sqn;
+  A.st2 = ws.st2;
   A.idx = idx;
   A.tw = ctx->d_tw[T];
   A.itw = ctx->d_itw[T];
@@ -472,97 +669,103 @@ int run_pass(fa_ctx* ctx, hipStream_t s, uint32_t slots, const uint32_t* idx, co
   A.itwc = ctx->d_itwc[T];
   A.nc = ctx->nc[T];
   A.count = slots;
+  A.dcount = dcount;
   A.nblk = nblk;
-  A.wrap32 = policy == FA_NORM_WRAP32;
-  A.accept = accept;
-  A.retry_count = (uint32_t*)ctx->retry_count.p;
-  A.retry_list = (uint32_t*)ctx->retry_list.p;
+  A.wrap32 = B.policy == FA_NORM_WRAP32;
+  A.accept = B.accept;
+  A.retry_count = retry_count;
+  A.retry_list = retry_list;
   A.item_base = item_base;
   A.half = ctx->wire == FA_WIRE_SPEC ? Q / 2u + 1u : Q / 2u;
-  A.dbg = dbg;
+  A.dbg = B.dbg;
   const uint32_t want = (slots + VERIFY_WAVES - 1) / VERIFY_WAVES;
   auto launch = [&](auto kernel) {
     const uint32_t grid = stride_grid(ctx, kernel, want);
     return timed(ctx, s, 2, [&] { hipLaunchKernelGGL(kernel, dim3(grid), dim3(VERIFY_WG), 0, s, A); });
   };
-  if (keys.prepared) return debug ? launch(verify_kernel<LOGN, true, true>) : launch(verify_kernel<LOGN, false, true>);
-  return debug ? launch(verify_kernel<LOGN, true, false>) : launch(verify_kernel<LOGN, false, false>);
+  if (B.keys.prepared) return B.debug ? launch(verify_kernel<LOGN, true, true>) : launch(verify_kernel<LOGN, false, true>);
+  return B.debug ? launch(verify_kernel<LOGN, true, false>) : launch(verify_kernel<LOGN, false, false>);
 }
 
-DebugOut debug_out(const fa_debug* dbgp, bool& debug)
+void set_debug(Batch& B, const fa_debug* dbgp)
 {
-  DebugOut dbg{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  debug = false;
+  B.dbg = DebugOut{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  B.debug = false;
   if (dbgp) {
-    dbg = DebugOut{ dbgp->c, dbgp->s2, dbgp->s1, (unsigned long long*)dbgp->norm_exact, dbgp->norm_wrap32, dbgp->status };
-    debug = dbg.c || dbg.s2 || dbg.s1 || dbg.norm_exact || dbg.norm_wrap32 || dbg.status;
+    B.dbg = DebugOut{ dbgp->c, dbgp->s2, dbgp->s1, (unsigned long long*)dbgp->norm_exact, dbgp->norm_wrap32, dbgp->status };
+    B.debug = B.dbg.c || B.dbg.s2 || B.dbg.s1 || B.dbg.norm_exact || B.dbg.norm_wrap32 || B.dbg.status;
   }
-  return dbg;
 }
 
-// Main passes of a batch, chunk by chunk, enqueued on `s` without synchronising. Items whose rejection
-// sampling ran out of squeezed blocks are left in ctx->retry_list for verify_finish.
+// B's arrays offset to the chunk of items starting at c0 (batches without an index list).
 template <int LOGN>
-int verify_enqueue(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
-                   const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+Batch window(const Batch& B, size_t c0)
 {
   using G = Geo<LOGN>;
-  constexpr int T = LOGN - 9;
-  constexpr size_t SIGLEN = LOGN == 9 ? 666 : 1280;
-  bool debug;
-  const DebugOut dbg = debug_out(dbgp, debug);
-  int rc;
-  if ((rc = ctx->retry_count.reserve(4))) return rc;
-  if ((rc = ctx->retry_list.reserve(std::max<size_t>(count, 1) * 4))) return rc;
-  HIP_TRY(hipMemsetAsync(ctx->retry_count.p, 0, 4, s));
+  Batch W = B;
+  if (W.keys.pk.base) W.keys.pk.base += c0 * W.keys.pk.stride;
+  if (W.keys.key_idx) W.keys.key_idx += c0;
+  W.sig.base += c0 * W.sig.stride;
+  if (W.msg_off) W.msg_off += c0;
+  else if (W.msg) W.msg += c0 * W.mlen;
+  W.accept += c0;
+  if (W.dbg.c) W.dbg.c += c0 * G::N;
+  if (W.dbg.s2) W.dbg.s2 += c0 * G::N;
+  if (W.dbg.s1) W.dbg.s1 += c0 * G::N;
+  if (W.dbg.norm_exact) W.dbg.norm_exact += c0;
+  if (W.dbg.norm_wrap32) W.dbg.norm_wrap32 += c0;
+  if (W.dbg.status) W.dbg.status += c0;
+  return W;
+}
 
-  for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
-    const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
-    DebugOut d = dbg;
-    if (d.c) d.c += c0 * G::N;
-    if (d.s2) d.s2 += c0 * G::N;
-    if (d.s1) d.s1 += c0 * G::N;
-    if (d.norm_exact) d.norm_exact += c0;
-    if (d.norm_wrap32) d.norm_wrap32 += c0;
-    if (d.status) d.status += c0;
-    KeySrc k = keys;  // this chunk's window of the per-item arrays
-    if (k.pk) k.pk += c0 * G::PKLEN;
-    if (k.key_idx) k.key_idx += c0;
-    rc = run_pass<LOGN>(ctx, s, slots, nullptr, k, msg_off ? msg : msg + c0 * mlen,
-                        msg_off ? msg_off + c0 : nullptr, mlen, sig + c0 * SIGLEN, ctx->hash_blocks[T], policy,
-                        accept + c0, d, debug, (uint32_t)c0);
+// Main passes of a batch, chunk by chunk, enqueued on `s` without synchronising. list == nullptr: the batch is
+// items [0, count) of B's arrays; else it is the `count` items list[0..count) of them (mixed batches: one class).
+// Items whose rejection sampling ran out of squeezed blocks are left in ws.retry_list (indices into B's arrays)
+// for verify_finish or retry_tail.
+template <int LOGN>
+int verify_enqueue(fa_ctx* ctx, const Workspace& ws, size_t count, const uint32_t* list, const Batch& B, hipStream_t s)
+{
+  constexpr int T = LOGN - 9;
+  HIP_TRY(hipMemsetAsync(ws.ctl, 0, 256, s));
+  const uint32_t chunk = std::min<uint32_t>(ctx->chunk, ws.cap_slots);
+  for (size_t c0 = 0; c0 < count; c0 += chunk) {
+    const uint32_t slots = (uint32_t)std::min<size_t>(chunk, count - c0);
+    int rc;
+    if (list)
+      rc = run_pass<LOGN>(ctx, ws, s, slots, list + c0, nullptr, false, B, ctx->hash_blocks[T], 0u, ws.ctl + CTL_RETRY, ws.retry_list);
+    else  // the kernels see the chunk's window of the arrays; the retry list gets indices into the whole arrays
+      rc = run_pass<LOGN>(ctx, ws, s, slots, nullptr, nullptr, false, window<LOGN>(B, c0), ctx->hash_blocks[T], (uint32_t)c0,
+                          ws.ctl + CTL_RETRY, ws.retry_list);
     if (rc) return rc;
   }
   return 0;
 }
 
 // Synchronises `s` and re-hashes the items verify_enqueue left over (probability ~1e-25 / ~1e-13 per item
-// at the default block counts) with twice as many blocks until none is left. Same arguments as the
-// verify_enqueue call it completes.
+// at the default block counts) with twice as many blocks until none is left. Same batch as the
+// verify_enqueue call it completes; `max_slots` = the largest pass of that call.
 template <int LOGN>
-int verify_finish(fa_ctx* ctx, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
-                  const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+int verify_finish(fa_ctx* ctx, Workspace& ws, uint32_t max_slots, size_t items, const Batch& B, hipStream_t s)
 {
   constexpr int T = LOGN - 9;
-  bool debug;
-  const DebugOut dbg = debug_out(dbgp, debug);
   int rc;
   uint32_t nblk = ctx->hash_blocks[T];
   for (;;) {
     uint32_t pending = 0;
-    HIP_TRY(hipMemcpyAsync(&pending, ctx->retry_count.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&pending, ws.ctl + CTL_RETRY, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (pending == 0) break;
     ctx->retried += pending;
     nblk *= 2;
-    DevBuf list;  // this round's list; the kernels refill ctx->retry_list
+    DevBuf list;  // this round's list; the kernels refill ws.retry_list
     if ((rc = list.reserve((size_t)pending * 4))) return rc;
-    rc = (int)hipMemcpyAsync(list.p, ctx->retry_list.p, (size_t)pending * 4, hipMemcpyDeviceToDevice, s);
-    if (!rc) rc = (int)hipMemsetAsync(ctx->retry_count.p, 0, 4, s);
-    for (uint32_t r0 = 0; !rc && r0 < pending; r0 += ctx->chunk) {
-      const uint32_t slots = std::min<uint32_t>(ctx->chunk, pending - r0);
-      rc = run_pass<LOGN>(ctx, s, slots, (const uint32_t*)list.p + r0, keys, msg, msg_off, mlen, sig, nblk, policy, accept,
-                          dbg, debug, 0u);
+    rc = (int)hipMemcpyAsync(list.p, ws.retry_list, (size_t)pending * 4, hipMemcpyDeviceToDevice, s);
+    if (!rc) rc = (int)hipMemsetAsync(ws.ctl, 0, 256, s);
+    const uint32_t chunk = std::min<uint32_t>(ctx->chunk, std::max<uint32_t>(max_slots, 128u));
+    if (!rc) rc = ws_from_ctx<LOGN>(ctx, std::min<uint32_t>(chunk, pending), nblk, items, ws);  // more blocks per item: a larger hraw
+    for (uint32_t r0 = 0; !rc && r0 < pending; r0 += chunk) {
+      const uint32_t slots = std::min<uint32_t>(chunk, pending - r0);
+      rc = run_pass<LOGN>(ctx, ws, s, slots, (const uint32_t*)list.p + r0, nullptr, true, B, nblk, 0u, ws.ctl + CTL_RETRY, ws.retry_list);
     }
     if (!rc) rc = (int)hipStreamSynchronize(s);
     list.release();
@@ -571,12 +774,36 @@ int verify_finish(fa_ctx* ctx, const KeySrc& keys, const uint8_t* msg, const uin
   return 0;
 }
 
+// The device-side counterpart of verify_finish, for callers that must not synchronise or allocate: one more pass,
+// over the items verify_enqueue queued (at most ws.tail_cap() of them), with twice the blocks per item, sized and
+// driven by the device-side count. What it cannot settle (more queued items than that, or an item that runs out
+// of blocks again: ~1e-50 at the default block counts) is counted as unresolved (retry_account_kernel); those
+// items keep accept = 0 and the caller learns their number from fa_finish / the call's return value.
 template <int LOGN>
-int verify_dev(fa_ctx* ctx, size_t count, const KeySrc& keys, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
-               const uint8_t* sig, int policy, uint8_t* accept, const fa_debug* dbgp, hipStream_t s)
+int retry_tail(fa_ctx* ctx, const Workspace& ws, const Batch& B, hipStream_t s)
 {
-  const int rc = verify_enqueue<LOGN>(ctx, count, keys, msg, msg_off, mlen, sig, policy, accept, dbgp, s);
-  return rc ? rc : verify_finish<LOGN>(ctx, keys, msg, msg_off, mlen, sig, policy, accept, dbgp, s);
+  constexpr int T = LOGN - 9;
+  const uint32_t cap = ws.tail_cap(), nblk = 2u * ctx->hash_blocks[T];
+  if (cap == 0 || (size_t)cap * nblk * 136 > ws.hraw_bytes) return FA_E_INTERNAL;
+  int rc = run_pass<LOGN>(ctx, ws, s, cap, ws.retry_list, ws.ctl + CTL_RETRY, true, B, nblk, 0u, ws.ctl + CTL_UNRESOLVED, ws.retry2_list);
+  if (rc) return rc;
+  hipLaunchKernelGGL(retry_account_kernel, dim3(1), dim3(1), 0, s, ws.ctl, cap, ctx->quiet ? (uint32_t*)nullptr : ctx->d_unresolved);
+  return (int)hipGetLastError();
+}
+
+// A whole device-resident verify call on the context's own workspace: main passes, then either the synchronising
+// host loop or (FA_OPT_ASYNC) the device-side retry pass.
+template <int LOGN>
+int verify_dev(fa_ctx* ctx, size_t count, const uint32_t* list, const Batch& B, hipStream_t s)
+{
+  constexpr int T = LOGN - 9;
+  const uint32_t max_slots = (uint32_t)std::min<size_t>(ctx->chunk, count);
+  Workspace ws;
+  int rc = ws_from_ctx<LOGN>(ctx, max_slots, ctx->hash_blocks[T], count, ws);
+  if (!rc) rc = verify_enqueue<LOGN>(ctx, ws, count, list, B, s);
+  if (rc) return rc;
+  if (ctx->async) return retry_tail<LOGN>(ctx, ws, B, s);
+  return verify_finish<LOGN>(ctx, ws, max_slots, count, B, s);
 }
 
 // hash_to_point for `count` (salt, message) pairs: SHAKE256 blocks, then rejection sampling; items that need
@@ -587,34 +814,35 @@ int hash_to_point_dev(fa_ctx* ctx, size_t count, const uint8_t* salt, const uint
 {
   constexpr int T = LOGN - 9;
   int rc;
-  if ((rc = ctx->retry_count.reserve(4))) return rc;
+  if ((rc = ctx->ctl.reserve(512))) return rc;
   if ((rc = ctx->retry_list.reserve(count * 4))) return rc;
-  HIP_TRY(hipMemsetAsync(ctx->retry_count.p, 0, 4, s));
-  const uint8_t* rows = salt - 1;  // hash_kernel reads the salt at bytes 1..40 of a row: rows of 40 bytes starting one byte early
-  auto pass = [&](uint32_t slots, const uint32_t* idx, const uint8_t* rows_, const uint8_t* msg_, const uint64_t* off_,
+  uint32_t* d_retry = (uint32_t*)ctx->ctl.p + CTL_RETRY;
+  HIP_TRY(hipMemsetAsync(ctx->ctl.p, 0, 256, s));
+  const Rows rows{ salt - 1, nullptr, 40u };  // hash_kernel reads the salt at bytes 1..40 of a row: rows of 40 bytes starting one byte early
+  auto pass = [&](uint32_t slots, const uint32_t* idx, const Rows& rows_, const uint8_t* msg_, const uint64_t* off_,
                   uint32_t nblk, uint16_t* c_, uint32_t item_base) -> int {
     int r = ctx->hraw.reserve((size_t)slots * nblk * 136);
     if (r) return r;
     r = timed(ctx, s, 1, [&] {
-      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, rows_, 40u, msg_, off_, mlen,
-                         idx, slots, nblk, (uint64_t*)ctx->hraw.p);
+      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, rows_, msg_, off_, mlen,
+                         idx, slots, (const uint32_t*)nullptr, nblk, (uint64_t*)ctx->hraw.p);
     });
     if (r) return r;
     const uint32_t grid = stride_grid(ctx, sample_kernel<LOGN>, (slots + VERIFY_WAVES - 1) / VERIFY_WAVES);
     hipLaunchKernelGGL(sample_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, (const uint64_t*)ctx->hraw.p, idx, slots, nblk,
-                       item_base, c_, (uint32_t*)ctx->retry_count.p, (uint32_t*)ctx->retry_list.p);
+                       item_base, c_, d_retry, (uint32_t*)ctx->retry_list.p);
     return (int)hipGetLastError();
   };
   for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
     const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
-    rc = pass(slots, nullptr, rows + c0 * 40, msg_off ? msg : msg + c0 * mlen, msg_off ? msg_off + c0 : nullptr,
+    rc = pass(slots, nullptr, Rows{ rows.base + c0 * 40, nullptr, 40u }, msg_off ? msg : msg + c0 * mlen, msg_off ? msg_off + c0 : nullptr,
               ctx->hash_blocks[T], c + (c0 << LOGN), (uint32_t)c0);
     if (rc) return rc;
   }
   uint32_t nblk = ctx->hash_blocks[T];
   for (;;) {
     uint32_t pending = 0;
-    HIP_TRY(hipMemcpyAsync(&pending, ctx->retry_count.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&pending, d_retry, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (pending == 0) break;
     ctx->retried += pending;
@@ -622,7 +850,7 @@ int hash_to_point_dev(fa_ctx* ctx, size_t count, const uint8_t* salt, const uint
     DevBuf list;
     if ((rc = list.reserve((size_t)pending * 4))) return rc;
     rc = (int)hipMemcpyAsync(list.p, ctx->retry_list.p, (size_t)pending * 4, hipMemcpyDeviceToDevice, s);
-    if (!rc) rc = (int)hipMemsetAsync(ctx->retry_count.p, 0, 4, s);
+    if (!rc) rc = (int)hipMemsetAsync(ctx->ctl.p, 0, 256, s);
     for (uint32_t r0 = 0; !rc && r0 < pending; r0 += ctx->chunk)
       rc = pass(std::min<uint32_t>(ctx->chunk, pending - r0), (const uint32_t*)list.p + r0, rows, msg, msg_off, nblk, c, 0u);
     if (!rc) rc = (int)hipStreamSynchronize(s);
@@ -655,18 +883,36 @@ template <int LOGN>
 int decode_sigs_dev(fa_ctx* ctx, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok, hipStream_t s)
 {
   constexpr size_t SIGLEN = LOGN == 9 ? 666 : 1280;
+  constexpr int T = LOGN - 9;
+  Workspace ws;
+  int rc = ws_from_ctx<LOGN>(ctx, (uint32_t)std::min<size_t>(ctx->chunk, count), ctx->hash_blocks[T], 1, ws);
+  if (rc) return rc;
   for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
     const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
-    int rc = decode_stage<LOGN>(ctx, s, slots, sig + c0 * SIGLEN, false);
+    rc = decode_stage<LOGN>(ctx, ws, s, slots, Rows{ sig + c0 * SIGLEN, nullptr, (uint32_t)SIGLEN }, nullptr, false);
     if (rc) return rc;
     const uint32_t grid = std::min<uint32_t>((slots + 3) / 4, (uint32_t)ctx->num_cu * 16u);
-    hipLaunchKernelGGL(untile_sig_kernel<LOGN>, dim3(grid), dim3(256), 0, s, sig + c0 * SIGLEN, (const uint16_t*)ctx->s2.p,
-                       (const uint8_t*)ctx->st2.p, slots, salt + c0 * 40, s2 + (c0 << LOGN), ok + c0);
+    hipLaunchKernelGGL(untile_sig_kernel<LOGN>, dim3(grid), dim3(256), 0, s, sig + c0 * SIGLEN, (const uint16_t*)ws.s2,
+                       (const uint8_t*)ws.st2, slots, salt + c0 * 40, s2 + (c0 << LOGN), ok + c0);
     HIP_TRY(hipGetLastError());
   }
   return 0;
 }
 
+}  // namespace
+
+namespace {
+int check_verify_args(const fa_ctx* ctx, int logn, size_t count, const void* keys, const uint8_t* msg, const uint64_t* msg_off,
+                      uint32_t mlen, const uint8_t* sig, int norm_policy, const uint8_t* accept)
+{
+  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!keys || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  if (count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (mlen > FA_MAX_MSG_LEN) return FA_E_ARG;  // the hash kernel counts message bytes in 32-bit signed integers
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -682,6 +928,7 @@ const char* fa_strerror(int code)
     case FA_E_LOGN: return "logn must be 9 (Falcon-512) or 10 (Falcon-1024)";
     case FA_E_ALIGN: return "device arrays must be 4-byte aligned";
     case FA_E_INTERNAL: return "internal error";
+    case FA_E_UNRESOLVED: return "items left unresolved by the device-side retry pass: verify them again with a synchronising call";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
@@ -708,6 +955,10 @@ int fa_ctx_create(int device, fa_ctx** out)
     for (int k = 0; k < 2 && !rc; k++) rc = (int)hipEventCreateWithFlags(&ctx->ev_ready[k], hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_ws, hipEventDisableTiming);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_unresolved, 256);
+    if (!rc) rc = (int)hipMemset(ctx->d_unresolved, 0, 256);
+    if (!rc) rc = (int)hipHostMalloc((void**)&ctx->h_word, 64, hipHostMallocDefault);
   }
   for (int t = 0; t < 2 && !rc; t++) try {
     const Tables tb = make_tables(9 + t);
@@ -737,21 +988,23 @@ void fa_ctx_destroy(fa_ctx* ctx)
 {
   if (!ctx) return;
   Guard g(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-  if (ctx->copy) (void)hipStreamSynchronize(ctx->copy);
+  (void)hipDeviceSynchronize();  // work enqueued on the caller's streams may still use the context's buffers
   for (auto& e : ctx->events) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
   for (int t = 0; t < 2; t++) {
     if (ctx->d_tw[t]) (void)hipFree(ctx->d_tw[t]);
     if (ctx->d_itw[t]) (void)hipFree(ctx->d_itw[t]);
     if (ctx->d_twc[t]) (void)hipFree(ctx->d_twc[t]);
     if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
   }
-  DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->retry_count, &ctx->retry_list, &ctx->slow_count, &ctx->slow_list, &ctx->h_pk,
-                     &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->spec_pk };
+  if (ctx->d_unresolved) (void)hipFree(ctx->d_unresolved);
+  if (ctx->h_word) (void)hipHostFree(ctx->h_word);
+  DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->ctl, &ctx->retry_list, &ctx->slow_list, &ctx->retry2_list,
+                     &ctx->part_list, &ctx->part_runs, &ctx->h_pk, &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_a, &ctx->h_b,
+                     &ctx->h_c, &ctx->h_off2, &ctx->h_off3, &ctx->h_tag, &ctx->spec_pk };
   for (DevBuf* b : bufs) b->release();
   for (auto& st : ctx->hs) {
     DevBuf* sb[] = { &st.pk, &st.sig, &st.msg, &st.off, &st.kidx, &st.accept };
@@ -768,6 +1021,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_ws) (void)hipEventDestroy(ctx->ev_ws);
   delete ctx;
 }
 
@@ -810,6 +1064,9 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
       if (value < 0 || value > 65536) return FA_E_ARG;
       ctx->grid_per_cu = (uint32_t)value;
       return 0;
+    case FA_OPT_ASYNC:
+      ctx->async = value != 0;
+      return 0;
     default:
       return FA_E_ARG;
   }
@@ -820,61 +1077,150 @@ int fa_get_profile(fa_ctx* ctx, fa_profile* out)
   if (!ctx || !out) return FA_E_ARG;
   Guard g(ctx->device);
   std::memset(out, 0, sizeof(*out));
-  for (auto& e : ctx->events) {
-    HIP_TRY(hipEventSynchronize(e.b));
+  int rc = 0;
+  // every recorded pair leaves ctx->events here, whatever happens: back to the pool, or destroyed
+  while (!ctx->events.empty()) {
+    const EventPair e = ctx->events.back();
+    ctx->events.pop_back();
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
-    double* acc[] = { &out->ms_decode, &out->ms_hash, &out->ms_verify, &out->ms_polymul };
-    uint32_t* cnt[] = { &out->launches_decode, &out->launches_hash, &out->launches_verify, &out->launches_polymul };
-    *acc[e.kind] += ms;
-    *cnt[e.kind] += 1;
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
+    if (!rc) rc = (int)hipEventSynchronize(e.b);
+    if (!rc) rc = (int)hipEventElapsedTime(&ms, e.a, e.b);
+    if (!rc) {
+      double* acc[] = { &out->ms_decode, &out->ms_hash, &out->ms_verify, &out->ms_polymul };
+      uint32_t* cnt[] = { &out->launches_decode, &out->launches_hash, &out->launches_verify, &out->launches_polymul };
+      *acc[e.kind] += ms;
+      *cnt[e.kind] += 1;
+    }
+    bool kept = false;
+    if (ctx->ev_free.size() < 4096) try {
+        ctx->ev_free.reserve(ctx->ev_free.size() + 2);
+        ctx->ev_free.push_back(e.a);
+        ctx->ev_free.push_back(e.b);
+        kept = true;
+      } catch (...) {
+      }
+    if (!kept) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
   }
-  ctx->events.clear();
   out->retried_items = ctx->retried;
   ctx->retried = 0;
-  return 0;
+  return rc;
+}
+
+int fa_finish(fa_ctx* ctx, void* stream, uint64_t* unresolved)
+{
+  if (!ctx) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_word, ctx->d_unresolved, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemsetAsync(ctx->d_unresolved, 0, 256, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const uint32_t n = *ctx->h_word;
+  if (unresolved) *unresolved = n;
+  return n ? FA_E_UNRESOLVED : 0;
 }
 
 int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
                        const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept,
                        const fa_debug* dbg, void* stream)
 {
-  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
-  if (logn != 9 && logn != 10) return FA_E_LOGN;
-  if (count == 0) return 0;
-  if (!pk || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
-  if (count > 0xFFFFFFFFull) return FA_E_ARG;
+  int rc = check_verify_args(ctx, logn, count, pk, msg, msg_off, mlen, sig, norm_policy, accept);
+  if (rc || count == 0) return rc;
   if (!aligned4(pk) || !aligned4(sig) || !aligned4(msg) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  KeySrc keys;
-  const int rc = keys_in_reference_form(ctx, logn, s, pk, count, &keys.pk);
-  if (rc) return rc;
-  return logn == 9 ? verify_dev<9>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
-                   : verify_dev<10>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
+  if ((rc = ws_begin(ctx, s))) return rc;
+  Batch B;
+  const uint8_t* pkr = pk;
+  if ((rc = keys_in_reference_form(ctx, logn, s, pk, count, &pkr))) return rc;
+  B.keys.pk = Rows{ pkr, nullptr, (uint32_t)fa_pkey_len(logn) };
+  B.sig = Rows{ sig, nullptr, (uint32_t)fa_sig_len(logn) };
+  B.msg = msg;
+  B.msg_off = msg_off;
+  B.mlen = mlen;
+  B.policy = norm_policy;
+  B.accept = accept;
+  set_debug(B, dbg);
+  rc = logn == 9 ? verify_dev<9>(ctx, count, nullptr, B, s) : verify_dev<10>(ctx, count, nullptr, B, s);
+  const int re = ws_end(ctx, s);
+  return rc ? rc : re;
 }
 
 int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, const uint32_t* key_idx,
                                 const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig,
                                 int norm_policy, uint8_t* accept, const fa_debug* dbg, void* stream)
 {
-  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
-  if (logn != 9 && logn != 10) return FA_E_LOGN;
-  if (count == 0) return 0;
-  if (!prepared || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
-  if (count > 0xFFFFFFFFull) return FA_E_ARG;
+  int rc = check_verify_args(ctx, logn, count, prepared, msg, msg_off, mlen, sig, norm_policy, accept);
+  if (rc || count == 0) return rc;
   if (!aligned4(prepared) || !aligned4(key_idx) || !aligned4(sig) || !aligned4(msg) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  KeySrc keys;
-  keys.prepared = prepared;
-  keys.key_idx = key_idx;
-  return logn == 9 ? verify_dev<9>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s)
-                   : verify_dev<10>(ctx, count, keys, msg, msg_off, mlen, sig, norm_policy, accept, dbg, s);
+  if ((rc = ws_begin(ctx, s))) return rc;
+  Batch B;
+  B.keys.prepared = prepared;
+  B.keys.key_idx = key_idx;
+  B.sig = Rows{ sig, nullptr, (uint32_t)fa_sig_len(logn) };
+  B.msg = msg;
+  B.msg_off = msg_off;
+  B.mlen = mlen;
+  B.policy = norm_policy;
+  B.accept = accept;
+  set_debug(B, dbg);
+  rc = logn == 9 ? verify_dev<9>(ctx, count, nullptr, B, s) : verify_dev<10>(ctx, count, nullptr, B, s);
+  const int re = ws_end(ctx, s);
+  return rc ? rc : re;
+}
+
+// Mixed Falcon-512 / Falcon-1024 batch, device-resident: the item indices are split by N on the GPU (three small
+// kernels, order-preserving), then each class runs through the ordinary passes with its index list.
+int fa_verify_mixed_dev(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
+                        const uint8_t* msg, const uint64_t* msg_off, const uint8_t* sig, const uint64_t* sig_off,
+                        int norm_policy, uint8_t* accept, void* stream)
+{
+  if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
+  if (count == 0) return 0;
+  if (!logn || !pk || !pk_off || !msg_off || !sig || !sig_off || !accept || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if (((uintptr_t)pk_off & 7u) || ((uintptr_t)msg_off & 7u) || ((uintptr_t)sig_off & 7u)) return FA_E_ALIGN;
+  if (ctx->wire != FA_WIRE_REFERENCE) return FA_E_ARG;  // the specification wire format is offered for single-N batches only
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ws_begin(ctx, s))) return rc;
+  const uint32_t n = (uint32_t)count, nruns = (n + PART_ITEMS - 1) / PART_ITEMS;
+  if ((rc = ctx->part_list.reserve((size_t)n * 4))) return rc;
+  if ((rc = ctx->part_runs.reserve(256 + (size_t)nruns * 4))) return rc;
+  uint32_t* totals = (uint32_t*)ctx->part_runs.p;  // [0] n9, [1] items whose tag is neither 9 nor 10
+  uint32_t* runs = totals + 64;
+  uint32_t* list = (uint32_t*)ctx->part_list.p;
+  HIP_TRY(hipMemsetAsync(totals, 0, 256, s));
+  hipLaunchKernelGGL(partition_count_kernel, dim3(nruns), dim3(PART_WG), 0, s, logn, n, runs, totals);
+  hipLaunchKernelGGL(partition_scan_kernel, dim3(1), dim3(PART_WG), 0, s, runs, nruns, totals);
+  hipLaunchKernelGGL(partition_write_kernel, dim3(nruns), dim3(PART_WG), 0, s, logn, n, (const uint32_t*)runs, (const uint32_t*)totals, list);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ctx->h_word, totals, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));  // the class sizes decide the passes
+  const uint32_t n9 = ctx->h_word[0], bad = ctx->h_word[1];
+  if (bad || n9 > n) {
+    (void)ws_end(ctx, s);
+    return FA_E_LOGN;
+  }
+  Batch B;
+  B.msg = msg;
+  B.msg_off = msg_off;
+  B.policy = norm_policy;
+  B.accept = accept;
+  B.keys.pk = Rows{ pk, pk_off, 0u };
+  B.sig = Rows{ sig, sig_off, 0u };
+  if (n9) rc = verify_dev<9>(ctx, n9, list, B, s);
+  if (!rc && n - n9) rc = verify_dev<10>(ctx, n - n9, list + n9, B, s);
+  const int re = ws_end(ctx, s);
+  return rc ? rc : re;
 }
 
 size_t fa_prepared_key_len(int logn) { return logn == 9 || logn == 10 ? (size_t)2 << logn : 0; }
@@ -890,6 +1236,7 @@ int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, 
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
+  if (const int rb = ws_begin(ctx, s)) return rb;  // FA_WIRE_SPEC repacks the keys into a buffer of the context
   const int T = logn - 9;
   const uint32_t n = (uint32_t)nkeys, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   {
@@ -906,7 +1253,8 @@ int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, 
     if (pk) FA_LAUNCH_PREP(10, true); else FA_LAUNCH_PREP(10, false);
   }
 #undef FA_LAUNCH_PREP
-  return (int)hipGetLastError();
+  const int rl = (int)hipGetLastError(), re = ws_end(ctx, s);
+  return rl ? rl : re;
 }
 
 int fa_prepare_keys(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, uint16_t* prepared)
@@ -953,14 +1301,16 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
       for (size_t i = 0; i < count; i++)
         if (key_idx[i] >= nkeys) return FA_E_ARG;
   }
+  if (mlen > FA_MAX_MSG_LEN) return FA_E_ARG;
   if (msg_off)
     for (size_t i = 0; i < count; i++)
-      if (msg_off[i + 1] < msg_off[i]) return FA_E_ARG;
+      if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > FA_MAX_MSG_LEN) return FA_E_ARG;
   Guard g(ctx->device);
   if (g.err) return g.err;
   const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);
   hipStream_t cs = ctx->stream, xs = ctx->copy;
   int rc;
+  if ((rc = ws_begin(ctx, cs))) return rc;
 
   const uint16_t* d_prepared = nullptr;
   if (prepared) {  // the key table is shared by all sub-batches: staged once, ahead of the first kernel
@@ -971,11 +1321,8 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
 
   struct Sub {  // one sub-batch: its window of the caller's arrays and where it sits on the device
     size_t c0 = 0, cnt = 0;
-    KeySrc keys;
-    const uint8_t* d_msg = nullptr;
-    const uint64_t* d_off = nullptr;
-    const uint8_t* d_sig = nullptr;
-    uint8_t* d_accept = nullptr;
+    Batch B;
+    Workspace ws;
     fa_debug d{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t dsz[6] = { 0, 0, 0, 0, 0, 0 };
   };
@@ -987,23 +1334,25 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     S = Sub{};
     S.c0 = k * (size_t)ctx->host_chunk;
     S.cnt = std::min<size_t>(ctx->host_chunk, count - S.c0);
+    S.B.policy = norm_policy;
+    S.B.mlen = mlen;
     int r;
     if ((r = st.sig.reserve(S.cnt * siglen + 8))) return r;
     if ((r = st.accept.reserve(S.cnt))) return r;
     if ((r = h2d(ctx->device, st.sig.p, sig + S.c0 * siglen, S.cnt * siglen, xs, st.pin_sig, ctx->host_threads))) return r;
-    S.d_sig = (const uint8_t*)st.sig.p;
-    S.d_accept = (uint8_t*)st.accept.p;
+    S.B.sig = Rows{ (const uint8_t*)st.sig.p, nullptr, (uint32_t)siglen };
+    S.B.accept = (uint8_t*)st.accept.p;
     if (prepared) {
-      S.keys.prepared = key_idx ? d_prepared : d_prepared + S.c0 * n;  // no index: item i uses key i
+      S.B.keys.prepared = key_idx ? d_prepared : d_prepared + S.c0 * n;  // no index: item i uses key i
       if (key_idx) {
         if ((r = st.kidx.reserve(S.cnt * 4))) return r;
         HIP_TRY(hipMemcpyAsync(st.kidx.p, key_idx + S.c0, S.cnt * 4, hipMemcpyHostToDevice, xs));
-        S.keys.key_idx = (const uint32_t*)st.kidx.p;
+        S.B.keys.key_idx = (const uint32_t*)st.kidx.p;
       }
     } else {
       if ((r = st.pk.reserve(S.cnt * pklen + 8))) return r;
       if ((r = h2d(ctx->device, st.pk.p, pk + S.c0 * pklen, S.cnt * pklen, xs, st.pin_pk, ctx->host_threads))) return r;
-      S.keys.pk = (const uint8_t*)st.pk.p;
+      S.B.keys.pk = Rows{ (const uint8_t*)st.pk.p, nullptr, (uint32_t)pklen };
     }
     // With offsets only the window [msg_off[c0], msg_off[c0 + cnt]) is staged; it lands at byte (first & 3)
     // of the staging buffer so that the device-side base pointer `stage - (first & ~3)` stays 4-byte
@@ -1014,11 +1363,11 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     uint8_t* stage = (uint8_t*)st.msg.p + (first & 3u);
     if ((r = h2d(ctx->device, stage, msg_off ? msg + first : msg + S.c0 * (size_t)mlen, msg_bytes, xs, st.pin_msg, ctx->host_threads)))
       return r;
-    S.d_msg = stage - first;
+    S.B.msg = stage - first;
     if (msg_off) {
       if ((r = st.off.reserve((S.cnt + 1) * 8))) return r;
       HIP_TRY(hipMemcpyAsync(st.off.p, msg_off + S.c0, (S.cnt + 1) * 8, hipMemcpyHostToDevice, xs));
-      S.d_off = (const uint64_t*)st.off.p;
+      S.B.msg_off = (const uint64_t*)st.off.p;
     }
     if (dbg) {
       void* const host[6] = { dbg->c, dbg->s2, dbg->s1, dbg->norm_exact, dbg->norm_wrap32, dbg->status };
@@ -1031,26 +1380,26 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
         *dev[i] = st.dbg[i].p;
         S.dsz[i] = sz[i];
       }
+      set_debug(S.B, &S.d);
     }
     HIP_TRY(hipEventRecord(ctx->ev_ready[k & 1], xs));
     return 0;
   };
+  const uint32_t max_slots = (uint32_t)std::min<size_t>({ (size_t)ctx->chunk, (size_t)ctx->host_chunk, count });
   auto launch = [&](size_t k, Sub& S) -> int {
     HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_ready[k & 1], 0));
-    if (S.keys.pk) {  // FA_WIRE_SPEC: this sub-batch's keys, repacked on the compute stream (one buffer: sub-batches run in turn)
-      const int r = keys_in_reference_form(ctx, logn, cs, S.keys.pk, S.cnt, &S.keys.pk);
+    if (S.B.keys.pk.base) {  // FA_WIRE_SPEC: this sub-batch's keys, repacked on the compute stream (one buffer: sub-batches run in turn)
+      const int r = keys_in_reference_form(ctx, logn, cs, S.B.keys.pk.base, S.cnt, &S.B.keys.pk.base);
       if (r) return r;
     }
-    const fa_debug* dp = dbg ? &S.d : nullptr;
-    return logn == 9 ? verify_enqueue<9>(ctx, S.cnt, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs)
-                     : verify_enqueue<10>(ctx, S.cnt, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs);
-  };
-  auto finish = [&](const Sub& S) -> int {
-    const fa_debug* dp = dbg ? &S.d : nullptr;
-    int r = logn == 9 ? verify_finish<9>(ctx, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs)
-                      : verify_finish<10>(ctx, S.keys, S.d_msg, S.d_off, mlen, S.d_sig, norm_policy, S.d_accept, dp, cs);
+    int r = logn == 9 ? ws_from_ctx<9>(ctx, max_slots, ctx->hash_blocks[0], S.cnt, S.ws) : ws_from_ctx<10>(ctx, max_slots, ctx->hash_blocks[1], S.cnt, S.ws);
     if (r) return r;
-    HIP_TRY(hipMemcpyAsync(accept + S.c0, S.d_accept, S.cnt, hipMemcpyDeviceToHost, cs));
+    return logn == 9 ? verify_enqueue<9>(ctx, S.ws, S.cnt, nullptr, S.B, cs) : verify_enqueue<10>(ctx, S.ws, S.cnt, nullptr, S.B, cs);
+  };
+  auto finish = [&](Sub& S) -> int {
+    int r = logn == 9 ? verify_finish<9>(ctx, S.ws, max_slots, S.cnt, S.B, cs) : verify_finish<10>(ctx, S.ws, max_slots, S.cnt, S.B, cs);
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(accept + S.c0, S.B.accept, S.cnt, hipMemcpyDeviceToHost, cs));
     if (dbg) {
       uint8_t* const host[6] = { (uint8_t*)dbg->c, (uint8_t*)dbg->s2, (uint8_t*)dbg->s1, (uint8_t*)dbg->norm_exact,
                                  (uint8_t*)dbg->norm_wrap32, (uint8_t*)dbg->status };
@@ -1124,52 +1473,46 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
 {
   if (!ctx) return FA_E_ARG;
   if (count == 0) return 0;
-  if (!logn || !pk || !pk_off || !msg_off || !sig || !sig_off || !accept) return FA_E_ARG;
-  for (size_t i = 0; i < count; i++)
+  if (!logn || !pk || !pk_off || !msg_off || !sig || !sig_off || !accept || count > 0xFFFFFFFFull) return FA_E_ARG;
+  // extent of each array: the records may sit anywhere in it, so the whole span up to the last byte used is staged
+  size_t pk_bytes = 0, sig_bytes = 0;
+  for (size_t i = 0; i < count; i++) {
     if (logn[i] != 9 && logn[i] != 10) return FA_E_LOGN;
-  try {
-  for (int ln = 9; ln <= 10; ln++) {  // partition by N on the host, one pass per class
-    const size_t pklen = fa_pkey_len(ln), siglen = fa_sig_len(ln);
-    std::vector<size_t> who;
-    for (size_t i = 0; i < count; i++)
-      if (logn[i] == ln) who.push_back(i);
-    if (who.empty()) continue;
-    const size_t nc = who.size();
-    std::vector<uint64_t> goff(nc + 1, 0);
-    for (size_t k = 0; k < nc; k++) {
-      if (msg_off[who[k] + 1] < msg_off[who[k]]) return FA_E_ARG;
-      goff[k + 1] = goff[k] + (msg_off[who[k] + 1] - msg_off[who[k]]);
-    }
-    if (goff[nc] && !msg) return FA_E_ARG;
-    std::vector<uint8_t> gpk(nc * pklen), gsig(nc * siglen), gmsg(std::max<uint64_t>(goff[nc], 1)), gacc(nc);
-    // the class's records, gathered into contiguous arrays by the context's host threads (contiguous ranges of items)
-    auto gather = [&](size_t k0, size_t k1) {
-      for (size_t k = k0; k < k1; k++) {
-        const size_t i = who[k];
-        std::memcpy(&gpk[k * pklen], pk + pk_off[i], pklen);
-        std::memcpy(&gsig[k * siglen], sig + sig_off[i], siglen);
-        const size_t ml = (size_t)(goff[k + 1] - goff[k]);
-        if (ml) std::memcpy(&gmsg[goff[k]], msg + msg_off[i], ml);
-      }
-    };
-    const size_t nt = std::max<size_t>(1, std::min<size_t>(ctx->host_threads, nc / 4096));
-    std::vector<std::thread> pool;
-    size_t started = 1;  // the calling thread takes range 0
-    try {
-      for (; started < nt; started++) pool.emplace_back(gather, nc * started / nt, nc * (started + 1) / nt);
-    } catch (...) {  // threads that could not be started: their ranges are done below
-    }
-    gather(0, nc / nt);
-    for (auto& th : pool) th.join();
-    for (size_t t = started; t < nt; t++) gather(nc * t / nt, nc * (t + 1) / nt);
-    const int rc = fa_verify_many(ctx, ln, nc, gpk.data(), gmsg.data(), goff.data(), 0, gsig.data(), norm_policy,
-                                  gacc.data(), nullptr);
-    if (rc) return rc;
-    for (size_t k = 0; k < nc; k++) accept[who[k]] = gacc[k];
+    if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > FA_MAX_MSG_LEN) return FA_E_ARG;
+    pk_bytes = std::max<size_t>(pk_bytes, (size_t)pk_off[i] + fa_pkey_len(logn[i]));
+    sig_bytes = std::max<size_t>(sig_bytes, (size_t)sig_off[i] + fa_sig_len(logn[i]));
   }
-  } catch (...) {  // std::bad_alloc of the host-side partition: no exception crosses the C ABI
-    return FA_E_INTERNAL;
-  }
+  const size_t msg_bytes = (size_t)msg_off[count];
+  if (msg_bytes && !msg) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = ws_begin(ctx, s))) return rc;
+  if ((rc = ctx->h_pk.reserve(pk_bytes + 16))) return rc;
+  if ((rc = ctx->h_sig.reserve(sig_bytes + 16))) return rc;
+  if ((rc = ctx->h_msg.reserve(msg_bytes + 16))) return rc;
+  if ((rc = ctx->h_off.reserve((count + 1) * 8))) return rc;
+  if ((rc = ctx->h_off2.reserve(count * 8))) return rc;
+  if ((rc = ctx->h_off3.reserve(count * 8))) return rc;
+  if ((rc = ctx->h_tag.reserve(count))) return rc;
+  if ((rc = ctx->h_a.reserve(count))) return rc;
+  if ((rc = h2d(ctx->device, ctx->h_pk.p, pk, pk_bytes, s, ctx->hs[0].pin_pk, ctx->host_threads))) return rc;
+  if ((rc = h2d(ctx->device, ctx->h_sig.p, sig, sig_bytes, s, ctx->hs[0].pin_sig, ctx->host_threads))) return rc;
+  if (msg_bytes && (rc = h2d(ctx->device, ctx->h_msg.p, msg, msg_bytes, s, ctx->hs[0].pin_msg, ctx->host_threads))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_off.p, msg_off, (count + 1) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_off2.p, pk_off, count * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_off3.p, sig_off, count * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tag.p, logn, count, hipMemcpyHostToDevice, s));
+  const bool was_async = ctx->async;
+  ctx->async = false;  // this call returns results: it settles every item before the copy back
+  rc = fa_verify_mixed_dev(ctx, count, (const uint8_t*)ctx->h_tag.p, (const uint8_t*)ctx->h_pk.p, (const uint64_t*)ctx->h_off2.p,
+                           (const uint8_t*)ctx->h_msg.p, (const uint64_t*)ctx->h_off.p, (const uint8_t*)ctx->h_sig.p,
+                           (const uint64_t*)ctx->h_off3.p, norm_policy, (uint8_t*)ctx->h_a.p, s);
+  ctx->async = was_async;
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(accept, ctx->h_a.p, count, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -1183,8 +1526,12 @@ int fa_hash_to_point_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t
   if (!aligned4(salt) || !aligned4(msg) || !aligned4(c) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
   Guard g(ctx->device);
   if (g.err) return g.err;
-  return logn == 9 ? hash_to_point_dev<9>(ctx, count, salt, msg, msg_off, mlen, c, (hipStream_t)stream)
-                   : hash_to_point_dev<10>(ctx, count, salt, msg, msg_off, mlen, c, (hipStream_t)stream);
+  if (mlen > FA_MAX_MSG_LEN) return FA_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (const int rb = ws_begin(ctx, s)) return rb;
+  const int rc = logn == 9 ? hash_to_point_dev<9>(ctx, count, salt, msg, msg_off, mlen, c, s) : hash_to_point_dev<10>(ctx, count, salt, msg, msg_off, mlen, c, s);
+  const int re = ws_end(ctx, s);
+  return rc ? rc : re;
 }
 
 int fa_hash_to_point_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* salt, const uint8_t* msg,
@@ -1323,6 +1670,7 @@ int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, 
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
+  if (const int rb = ws_begin(ctx, s)) return rb;  // FA_WIRE_SPEC repacks the keys into a buffer of the context
   const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   {
     const int rc = keys_in_reference_form(ctx, logn, s, pk, count, &pk);
@@ -1332,7 +1680,8 @@ int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, 
     hipLaunchKernelGGL(decode_pkeys_kernel<9>, dim3(stride_grid(ctx, decode_pkeys_kernel<9>, want)), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
   else
     hipLaunchKernelGGL(decode_pkeys_kernel<10>, dim3(stride_grid(ctx, decode_pkeys_kernel<10>, want)), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
-  return (int)hipGetLastError();
+  const int rl = (int)hipGetLastError(), re = ws_end(ctx, s);
+  return rl ? rl : re;
 }
 
 int fa_decode_pkeys(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, uint16_t* h, uint8_t* ok)
@@ -1368,8 +1717,11 @@ int fa_decode_sigs_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, 
   if (!aligned4(sig) || ((uintptr_t)s2 & 1u)) return FA_E_ALIGN;
   Guard g(ctx->device);
   if (g.err) return g.err;
-  return logn == 9 ? decode_sigs_dev<9>(ctx, count, sig, salt, s2, ok, (hipStream_t)stream)
-                   : decode_sigs_dev<10>(ctx, count, sig, salt, s2, ok, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;  // the decoders write the context's workspace, which the untiling kernel reads
+  if (const int rb = ws_begin(ctx, s)) return rb;
+  const int rc = logn == 9 ? decode_sigs_dev<9>(ctx, count, sig, salt, s2, ok, s) : decode_sigs_dev<10>(ctx, count, sig, salt, s2, ok, s);
+  const int re = ws_end(ctx, s);
+  return rc ? rc : re;
 }
 
 int fa_decode_sigs(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok)

@@ -39,6 +39,18 @@ __host__ __device__ __forceinline__ size_t s2_tile_offset(uint32_t slot, uint32_
 template <int LOGN>
 __host__ __device__ __forceinline__ size_t s2_tile_elems(size_t slots) { return ((slots + 63u) / 64u * 64u) << LOGN; }
 
+// Where the records (signatures, public keys, salts) of a pass live: the record of item i starts at base + off[i]
+// when `off` is given (mixed Falcon-512/1024 batches, fa_verify_mixed_dev), else at base + i * stride.
+struct Rows {
+  const uint8_t* base;
+  const uint64_t* off;  // nullable
+  uint32_t stride;
+  __device__ __forceinline__ const uint8_t* at(uint32_t item) const
+  {
+    return base + (off ? (size_t)off[item] : (size_t)item * stride);
+  }
+};
+
 // MSB-first bit reader over the signature body (bytes 41..siglen-1), fed by aligned 16-byte loads.
 struct BitReader {
   const uint4* base;     // 16-byte aligned address at or below body byte 0
@@ -98,26 +110,27 @@ struct BitReader {
 };
 
 // Generic decoder (every rule, including the k >= 8 windows), one signature per lane. sig rows -> s2 (u16,
-// lifted, tiled layout, written 8 coefficients = 16 bytes at a time), sqn[o] = sum s2^2, st[o]. idx
-// (nullable) maps slot -> item; outputs go to index o = slot, or o = item when `scatter` (the fix-up pass
-// behind decode_fast_kernel). The number of slots is min(count, *dcount) when dcount is given (a
-// device-side list length). For an item that fails, the s2 row is left unspecified (nothing reads it).
+// lifted, tiled layout, written 8 coefficients = 16 bytes at a time), sqn[slot] = sum s2^2, st[slot]. Thread t
+// works on workspace slot list[t] (list nullable: slot t; the list is the fix-up queue of decode_fast_kernel),
+// whose signature is item idx[slot] (idx nullable: item = slot). The number of threads that work is
+// min(count, *dcount) when dcount is given (a device-side list length). For an item that fails, the s2 row
+// is left unspecified (nothing reads it).
 template <int LOGN>
-__global__ __launch_bounds__(DECODE_WG) void decode_kernel(const uint8_t* __restrict__ sig,
+__global__ __launch_bounds__(DECODE_WG) void decode_kernel(const Rows sig, const uint32_t* __restrict__ list,
                                                            const uint32_t* __restrict__ idx, uint32_t count,
-                                                           const uint32_t* __restrict__ dcount, bool scatter,
+                                                           const uint32_t* __restrict__ dcount,
                                                            uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
                                                            uint8_t* __restrict__ st, uint32_t spec)
 {
   constexpr int N = 1 << LOGN;
   constexpr int SIGLEN = LOGN == 9 ? 666 : 1280;
   constexpr int32_t SLEN = 8 * SIGLEN;  // in bits, decoding.hpp:274
-  uint32_t slot = blockIdx.x * DECODE_WG + threadIdx.x;
+  const uint32_t t = blockIdx.x * DECODE_WG + threadIdx.x;
   if (dcount) count = min(count, *dcount);
-  if (slot >= count) return;
-  const uint32_t item = idx ? idx[slot] : slot;
-  if (scatter) slot = item;
-  const uint8_t* row = sig + (size_t)item * SIGLEN;
+  if (t >= count) return;
+  const uint32_t slot = list ? list[t] : t;        // workspace slot (list: the fix-up pass behind decode_fast_kernel)
+  const uint32_t item = idx ? idx[slot] : slot;    // slot -> item of the caller's arrays
+  const uint8_t* row = sig.at(item);
 
   if (row[0] != (uint8_t)(0x30 | LOGN)) {  // decoding.hpp:376-382
     st[slot] = ST_BAD_SIG_HEADER;
@@ -245,7 +258,8 @@ constexpr uint32_t DF_AHEAD = 72;  // bytes beyond the cursor a chunk may touch:
 
 // The kernel's body for workgroup (= wave) `block`; also run by front_small_kernel (capi.hip).
 template <int LOGN>
-__device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* __restrict__ sig, uint32_t count,
+__device__ __forceinline__ void decode_fast_body(uint32_t block, const Rows& sig, const uint32_t* __restrict__ idx,
+                                                 uint32_t count, const uint32_t* __restrict__ dcount,
                                                  uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
                                                  uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
                                                  uint32_t* __restrict__ slow_list, uint32_t spec)
@@ -260,11 +274,15 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
   const uint32_t lane = threadIdx.x;
   const uint32_t slot0 = block * 64u;
   const uint32_t slot = slot0 + lane;
+  if (dcount) count = min(count, *dcount);  // device-side number of slots (mixed batches); wave-uniform
+  if (slot0 >= count) return;
   const bool live = slot < count;
   const uint32_t row = live ? slot : count - 1u;  // idle lanes shadow the last row and write nothing
+  // signature body of workspace slot r (slot -> item through idx, item -> address through sig)
+  auto body_of = [&](uint32_t r) -> const uint8_t* { return sig.at(idx ? idx[r] : r) + 41; };
 
   // geometry of this lane's row, relative to the 16-byte aligned address at or below the body (`lbase` below)
-  const uint8_t* body = sig + (size_t)row * SIGLEN + 41;
+  const uint8_t* body = body_of(row);
   const uint32_t boff = (uint32_t)((uintptr_t)body & 15u);
   const uint32_t end_bits = 8u * (boff + BODY);        // first bit past the signature
   const uint32_t plast = (boff + BODY - 1u) >> 4;      // last piece holding a byte of the row (never read past it)
@@ -291,7 +309,7 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
     uint4 v[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      const uint8_t* b = sig + (size_t)min(slot0 + 8u * t + (lane >> 3), count - 1u) * SIGLEN + 41;
+      const uint8_t* b = body_of(min(slot0 + 8u * t + (lane >> 3), count - 1u));
       const uint32_t last = ((uint32_t)((uintptr_t)b & 15u) + BODY - 1u) >> 4;
       v[t] = ((const uint4*)(b - ((uintptr_t)b & 15u)))[min(lane & 7u, last)];  // lanes 6, 7 of a group load too (and drop it):
     }                                                                          // unconditional loads issue back to back
@@ -315,7 +333,7 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
   const uint4* lbase[4];  // aligned base of the row this lane helps to load in round t
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const uint8_t* b = sig + (size_t)min(slot0 + 16u * t + (lane >> 2), count - 1u) * SIGLEN + 41;
+    const uint8_t* b = body_of(min(slot0 + 16u * t + (lane >> 2), count - 1u));
     lbase[t] = (const uint4*)(b - ((uintptr_t)b & 15u));
   }
   uint32_t want = 0;
@@ -398,7 +416,7 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
   }
 
   if (!live) return;
-  if (sig[(size_t)slot * SIGLEN] != (uint8_t)(0x30 | LOGN)) {  // decoding.hpp:376-382
+  if (body[-41] != (uint8_t)(0x30 | LOGN)) {  // decoding.hpp:376-382 (live lane: body is this slot's own row)
     st[slot] = ST_BAD_SIG_HEADER;
     sqn[slot] = 0u;
     return;
@@ -428,12 +446,13 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const uint8_t* 
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(64) void decode_fast_kernel(const uint8_t* __restrict__ sig, uint32_t count,
+__global__ __launch_bounds__(64) void decode_fast_kernel(const Rows sig, const uint32_t* __restrict__ idx, uint32_t count,
+                                                         const uint32_t* __restrict__ dcount,
                                                          uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
                                                          uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
                                                          uint32_t* __restrict__ slow_list, uint32_t spec)
 {
-  decode_fast_body<LOGN>(blockIdx.x, sig, count, s2, sqn, st, slow_count, slow_list, spec);
+  decode_fast_body<LOGN>(blockIdx.x, sig, idx, count, dcount, s2, sqn, st, slow_count, slow_list, spec);
 }
 
 // ---- decoding::decode_sig<N> (decoding.hpp:369-391) as a batched operator: the last step ----

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "decode_kernel.hpp"  // Rows
+
 namespace fa {
 
 __constant__ uint32_t KECCAK_RC_LO[24] = {
@@ -118,7 +120,7 @@ __device__ __forceinline__ uint32_t load_bytes4(const uint32_t* base, uint32_t a
 
 constexpr int HASH_WG = 256;
 
-// One lane per item. sig rows: salt = bytes 1..40 (decoding.hpp:389). Messages: fixed length
+// One lane per item. sig rows (a Rows map, decode_kernel.hpp): salt = bytes 1..40 (decoding.hpp:389). Messages: fixed length
 // mlen at msg + item*mlen when msg_off == nullptr, else msg + msg_off[item] with length
 // msg_off[item+1] - msg_off[item] (may differ per lane: the absorb loop diverges, the squeeze
 // loop does not). idx (nullable) maps output slot -> item.
@@ -131,14 +133,16 @@ constexpr int HASH_WG = 256;
 // The kernel's body for workgroup `block` of WG threads (a template so that front_small_kernel, decode_kernel.hpp's
 // companion for small batches, can run it in 64-thread workgroups beside the decoder).
 template <int WG>
-__device__ __forceinline__ void hash_body(uint32_t block, const uint8_t* __restrict__ sig, uint32_t siglen,
+__device__ __forceinline__ void hash_body(uint32_t block, const Rows& sig,
                                           const uint8_t* __restrict__ msg, const uint64_t* __restrict__ msg_off, uint32_t mlen,
-                                          const uint32_t* __restrict__ idx, uint32_t count, uint32_t nblk,
-                                          uint64_t* __restrict__ hraw)
+                                          const uint32_t* __restrict__ idx, uint32_t count, const uint32_t* __restrict__ dcount,
+                                          uint32_t nblk, uint64_t* __restrict__ hraw)
 {
   __shared__ uint64_t stage[WG / 64][64 * 17];
   const uint32_t slot = block * WG + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (dcount) count = min(count, *dcount);  // device-side number of slots (retry pass, mixed batches)
+  if (block * WG + wave * 64u >= count) return;  // wave-uniform: nothing for this wave (no workgroup barrier below)
   const bool live = slot < count;
   const uint32_t item = live ? (idx ? idx[slot] : slot) : 0u;
 
@@ -148,7 +152,7 @@ __device__ __forceinline__ void hash_body(uint32_t block, const uint8_t* __restr
 
   if (live) {
     // --- absorb salt || msg || pad, 136 bytes at a time (hashing.hpp:30-33) ---
-    const uint8_t* sp = sig + (size_t)item * siglen + 1;
+    const uint8_t* sp = sig.at(item) + 1;
     const uint32_t sal = (uint32_t)((uintptr_t)sp & 3u);
     const uint32_t* sbase = (const uint32_t*)(sp - sal);
     const uint8_t* mp;
@@ -211,13 +215,13 @@ __device__ __forceinline__ void hash_body(uint32_t block, const uint8_t* __restr
   }
 }
 
-__global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const uint8_t* __restrict__ sig, uint32_t siglen,
-                                                       const uint8_t* __restrict__ msg,
+__global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const Rows sig, const uint8_t* __restrict__ msg,
                                                        const uint64_t* __restrict__ msg_off, uint32_t mlen,
                                                        const uint32_t* __restrict__ idx, uint32_t count,
-                                                       uint32_t nblk, uint64_t* __restrict__ hraw)
+                                                       const uint32_t* __restrict__ dcount, uint32_t nblk,
+                                                       uint64_t* __restrict__ hraw)
 {
-  hash_body<HASH_WG>(blockIdx.x, sig, siglen, msg, msg_off, mlen, idx, count, nblk, hraw);
+  hash_body<HASH_WG>(blockIdx.x, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
 }
 
 }  // namespace fa

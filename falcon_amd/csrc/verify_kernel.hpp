@@ -394,7 +394,7 @@ struct DebugOut {  // device pointers, any may be null
 
 template <int LOGN>
 struct VerifyArgs {
-  const uint8_t* pk;        // [items][PKLEN]                       (packed-key kernels)
+  Rows pk;                  // packed public keys, one record per item (packed-key kernels)
   const uint16_t* prepared; // [keys][N] prepared keys, see prepare_keys_kernel (prepared-key kernels)
   const uint32_t* key_idx;  // item -> key, nullable (then key = item_base + item)
   const uint64_t* hraw;     // [slots][nblk*17]
@@ -408,6 +408,7 @@ struct VerifyArgs {
   const Tw* itwc;
   NttConsts nc;
   uint32_t count;           // slots
+  const uint32_t* dcount;   // nullable: device-side number of slots, count = min(count, *dcount) (retry pass, mixed batches)
   uint32_t nblk;
   uint32_t wrap32;          // norm policy
   uint32_t item_base;       // added to item in retry_list entries (chunked main pass)
@@ -549,7 +550,7 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   if constexpr (PREPARED) {
     r.pal = 0u;  // (the key row was requested first, above)
   } else {
-    const uint8_t* pkrow = A.pk + (size_t)r.item * G::PKLEN;
+    const uint8_t* pkrow = A.pk.at(r.item);
     r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
     const uint32_t* pbase = (const uint32_t*)(pkrow - r.pal);
     const uint32_t last_dw = (r.pal + (uint32_t)G::PKLEN - 1u) >> 2;
@@ -586,7 +587,8 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
 
   uint32_t slot = blockIdx.x * VERIFY_WAVES + wave;
-  if (slot >= A.count) return;
+  const uint32_t count = A.dcount ? min(A.count, *A.dcount) : A.count;
+  if (slot >= count) return;
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED>(A, slot, lane, cur);
   // The first item's loads are waited for here, once, before the loop. Without this the loop header inherits
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
 
   while (true) {
     const uint32_t nslot = slot + nwaves;
-    const bool more = nslot < A.count;  // wave-uniform
+    const bool more = nslot < count;  // wave-uniform
     ItemRegs<LOGN> nxt;
     if (more) prefetch_item<LOGN, PREPARED>(A, nslot, lane, nxt);
 
@@ -641,8 +643,11 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
           sample(d < ndw ? hrow[d] : 0xffffffffu);
         }
       }
-      if (have < (uint32_t)N) {  // vanishingly rare: the host re-hashes this item with more blocks
-        if (lane == 0) A.retry_list[atomicAdd(A.retry_count, 1u)] = A.item_base + item;
+      if (have < (uint32_t)N) {  // vanishingly rare: this item is hashed again with more blocks (host loop or retry pass)
+        if (lane == 0) {
+          A.retry_list[atomicAdd(A.retry_count, 1u)] = A.item_base + item;
+          A.accept[item] = 0;  // defined until then
+        }
         done = true;
       }
     }

@@ -11,6 +11,10 @@
  * Return value of every int function: 0 ok; < 0 invalid argument (FA_E_*); > 0 a hipError_t.
  * A context belongs to one GPU and is used by one host thread at a time; contexts on
  * different GPUs are independent (batches shard by item, no collective is involved).
+ * Streams: the device-resident (_dev) entry points enqueue on the caller's stream and share the context's one
+ * workspace. Calls on different streams are ordered by the library itself (each waits, on the device, for the
+ * previous call's last use of the workspace), so they are safe but do not overlap; for concurrent batches on
+ * one GPU use one context per stream.
  */
 #ifndef FALCON_AMD_H
 #define FALCON_AMD_H
@@ -26,6 +30,12 @@ extern "C" {
 #define FA_E_LOGN (-2)      /* logn is neither 9 nor 10 */
 #define FA_E_ALIGN (-3)     /* a device array is not 4-byte aligned */
 #define FA_E_INTERNAL (-4)
+#define FA_E_UNRESOLVED (-5) /* asynchronous / allocation-free calls: items the device-side retry pass could not settle (see fa_finish) */
+
+/* Longest message any entry point takes: the hash kernel counts the bytes of salt || message in 32-bit signed
+ * integers (the reference takes a size_t mlen, hashing.hpp:16-21). Host entry points return FA_E_ARG beyond it; with
+ * device-side offsets (msg_off on the GPU) the limit is the caller's to keep. */
+#define FA_MAX_MSG_LEN 0x7fffff00u
 
 /* Norm policy: verification.hpp:70-79 sums the squared norm in int32_t,
  * which overflows for most invalid signatures, so the reference's reject flag depends on its
@@ -53,6 +63,7 @@ extern "C" {
 #define FA_OPT_WIRE_FORMAT 8     /* FA_WIRE_REFERENCE (default) or FA_WIRE_SPEC, see below */
 #define FA_OPT_SMALL_BATCH_ITEMS 10 /* passes of at most this many items run decoder and hash waves in one kernel (latency), default 2^15; 0: never */
 #define FA_OPT_GRID_PER_CU 9     /* workgroups per CU of the one-wave-per-item kernels; 0 (default): 12 x what the GPU holds at once */
+#define FA_OPT_ASYNC 11          /* 1: the device-resident verify calls return without synchronising their stream, see fa_finish; default 0 */
 
 /* Wire format of public keys and signatures, for every entry point that parses them (verify, prepare_keys from
  * encoded keys, decode_pkeys, decode_sigs). The reference is not wire compatible with the Falcon specification
@@ -106,10 +117,22 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
 /* The same with every pointer (including those inside dbg) a device pointer on ctx's GPU; arrays
  * must be 4-byte aligned. Work is enqueued on `stream` (a hipStream_t, NULL = default stream); the
  * call synchronises that stream once before returning (it has to learn whether any item needs the
- * re-hash pass). This is the entry point the throughput figure is measured on. */
+ * re-hash pass), unless FA_OPT_ASYNC is set (see fa_finish). This is the entry point the throughput figure
+ * is measured on. */
 int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
                        const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
                        uint8_t* accept, const fa_debug* dbg, void* stream);
+
+/* Asynchronous use (FA_OPT_ASYNC = 1): fa_verify_many_dev, fa_verify_many_prepared_dev and fa_verify_mixed_dev (the
+ * latter after one early synchronisation to learn the class sizes) return as soon as their kernels are enqueued, so
+ * a caller can queue batch after batch. The rare item whose rejection sampling needs more SHAKE256 blocks than were
+ * squeezed up front (about 1e-25 / 1e-13 of Falcon-512 / Falcon-1024 items at the default block counts) is then not
+ * settled by a host-side loop but by one more pass enqueued behind the batch, with twice the blocks, for at most
+ * min(4096, half the pass size) such items. fa_finish synchronises `stream` and reports how many items of the calls
+ * since the last fa_finish even that pass left unresolved (their accept byte is 0): returns 0 if none, else
+ * FA_E_UNRESOLVED with the count in *unresolved (nullable) -- verify those batches again synchronously. No reference
+ * counterpart: the reference is synchronous by nature. */
+int fa_finish(fa_ctx* ctx, void* stream, uint64_t* unresolved);
 
 /* ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
  * For callers that keep public keys decoded and verify many signatures per key (falcon.hpp:226-229,
@@ -152,11 +175,20 @@ int fa_compute_public_keys_dev(fa_ctx* ctx, int logn, size_t count, const int32_
                                void* stream);
 
 /* Mixed Falcon-512 / Falcon-1024 batch, host buffers: logn[i] in {9,10}; item i's key, signature and
- * message are pk[pk_off[i]..], sig[sig_off[i]..], msg[msg_off[i]..msg_off[i+1]). The host splits the
- * batch by N and runs one pass per class. */
+ * message are pk[pk_off[i]..], sig[sig_off[i]..], msg[msg_off[i]..msg_off[i+1]). The arrays are copied to the GPU
+ * as they are (up to the last byte any record uses) and verified by fa_verify_mixed_dev. */
 int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
                     const uint8_t* msg, const uint64_t* msg_off, const uint8_t* sig, const uint64_t* sig_off,
                     int norm_policy, uint8_t* accept);
+
+/* The same with every pointer a device pointer on ctx's GPU (falcon.hpp:230-249 serves both N from one template;
+ * BASELINE.json configs[4]: the mixed 512+1024 batch). Records may sit at any byte offset; the offset arrays must
+ * be 8-byte aligned. The item indices are split by N on the GPU (order-preserving), the call synchronises `stream`
+ * once to learn the class sizes, then each class runs through the same passes as fa_verify_many_dev, reading its
+ * records in place through the offsets -- nothing is gathered or copied. Reference wire format only. */
+int fa_verify_mixed_dev(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
+                        const uint8_t* msg, const uint64_t* msg_off, const uint8_t* sig, const uint64_t* sig_off,
+                        int norm_policy, uint8_t* accept, void* stream);
 
 /* c[i] = a[i] * b[i] in Z_q[x]/(x^n+1), q = 12289, coefficients u16 (any value; taken mod q as the
  * ff_t constructor does, ff.hpp:69-76), results canonical. The composition ntt::ntt, polynomial::mul,
