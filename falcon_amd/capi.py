@@ -25,7 +25,7 @@ EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile",
            "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev", "fa_compute_public_keys",
            "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister",
            "fa_ntt_many", "fa_ntt_many_dev", "fa_decode_pkeys", "fa_decode_pkeys_dev", "fa_decode_sigs", "fa_decode_sigs_dev",
-           "fa_finish", "fa_verify_mixed_dev"]
+           "fa_finish", "fa_verify_many_dev_noalloc", "fa_verify_mixed_dev"]
 
 
 class FaDebug(ctypes.Structure):
@@ -70,6 +70,7 @@ def load_library():
     lib.fa_verify_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug), vp]
     lib.fa_verify_mixed.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.fa_verify_mixed_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.fa_verify_many_dev_noalloc.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, i32, vp, vp]
     lib.fa_finish.argtypes = [vp, vp, ctypes.POINTER(u64)]
     lib.fa_polymul_many.argtypes = [vp, i32, sz, vp, vp, vp]
     lib.fa_polymul_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
@@ -378,6 +379,13 @@ class Context:
                                          norm_policy, accept_ptr, ctypes.byref(dbg) if dbg is not None else None,
                                          stream or None)
         _check(rc, "fa_verify_many_dev")
+
+    def verify_many_dev_noalloc(self, logn, count, pk_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr, accept_ptr,
+                                norm_policy=NORM_EXACT64, stream=0):
+        """fa_verify_many_dev_noalloc: the same on the library's static scratch array, no device allocation."""
+        rc = self.lib.fa_verify_many_dev_noalloc(self.handle, logn, count, pk_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr,
+                                                 norm_policy, accept_ptr, stream or None)
+        _check(rc, "fa_verify_many_dev_noalloc")
 
     def verify_mixed_dev(self, count, logn_ptr, pk_ptr, pk_off_ptr, msg_ptr, msg_off_ptr, sig_ptr, sig_off_ptr, accept_ptr,
                          norm_policy=NORM_EXACT64, stream=0):

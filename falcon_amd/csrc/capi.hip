@@ -394,6 +394,7 @@ struct fa_ctx {
   DevBuf part_list, part_runs;  // mixed batches: the item indices split by N, per-run counts + totals
   uint32_t* d_unresolved = nullptr;  // running total of unresolved items of asynchronous calls (256-byte block)
   uint32_t* h_word = nullptr;        // pinned host words for small device-to-host reads
+  unsigned char* scratch = nullptr;  // this device's copy of the library's static scratch array (hipGetSymbolAddress)
   // staging for the host-buffer entry points; the verify pipeline double-buffers its per-item inputs
   struct HostStage {
     DevBuf pk, sig, msg, off, kidx, accept, dbg[6];
@@ -901,7 +902,62 @@ int decode_sigs_dev(fa_ctx* ctx, size_t count, const uint8_t* sig, uint8_t* salt
 
 }  // namespace
 
+// ---- allocation-free entry point: static device scratch (task item 7; no counterpart in the reference) ----
+// The pipeline workspace of a batch of at most FA_NOALLOC_MAX_ITEMS items of either N, carved out of one static
+// device array that every GPU the library runs on holds until the process ends. `scratch` is a host-side stand-in
+// for the symbol: the device address is taken with hipGetSymbolAddress, per device, at context creation.
 namespace {
+constexpr size_t NOALLOC_ITEMS = FA_NOALLOC_MAX_ITEMS;
+constexpr size_t SC_CTL = 0;                                                        // 512 bytes of counters
+constexpr size_t SC_S2 = 512;                                                       // tiled s2, Falcon-1024 rows
+constexpr size_t SC_HRAW = SC_S2 + align256(NOALLOC_ITEMS * 1024 * 2);              // 17 blocks per item
+constexpr size_t SC_SQN = SC_HRAW + align256(NOALLOC_ITEMS * 17 * 136);
+constexpr size_t SC_ST2 = SC_SQN + align256(NOALLOC_ITEMS * 4);
+constexpr size_t SC_RETRY = SC_ST2 + align256(NOALLOC_ITEMS);
+constexpr size_t SC_SLOW = SC_RETRY + align256(NOALLOC_ITEMS * 4);
+constexpr size_t SC_RETRY2 = SC_SLOW + align256(NOALLOC_ITEMS * 4);
+constexpr size_t SC_BYTES = SC_RETRY2 + align256(NOALLOC_ITEMS * 4);
+static_assert(NOALLOC_ITEMS % 64 == 0 && NOALLOC_ITEMS >= 128 && SC_BYTES < ((size_t)20 << 20), "scratch layout");
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[SC_BYTES];
+
+namespace {
+std::mutex g_scratch_lock;
+unsigned char* g_scratch_ptr[FA_MAX_DEVICES] = {};  // per device: each GPU holds its own copy of the array at its own address
+
+// The device address of `scratch` on `device` (which must be current), asked once per device.
+int scratch_address(int device, unsigned char** out)
+{
+  if (device < 0 || device >= FA_MAX_DEVICES) return FA_E_ARG;
+  std::lock_guard<std::mutex> hold(g_scratch_lock);
+  if (!g_scratch_ptr[device]) {
+    unsigned char* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    if (!p) return FA_E_INTERNAL;
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return 0;
+}
+
+// The scratch array as a pipeline workspace (hash_blocks up to 17 per item for the main pass).
+Workspace ws_from_scratch(unsigned char* sp)
+{
+  Workspace ws;
+  ws.ctl = (uint32_t*)(sp + SC_CTL);
+  ws.slow_count = ws.ctl + CTL_WORDS;
+  ws.s2 = (uint16_t*)(sp + SC_S2);
+  ws.hraw = (uint64_t*)(sp + SC_HRAW);
+  ws.hraw_bytes = NOALLOC_ITEMS * 17 * 136;
+  ws.sqn = (uint32_t*)(sp + SC_SQN);
+  ws.st2 = (uint8_t*)(sp + SC_ST2);
+  ws.retry_list = (uint32_t*)(sp + SC_RETRY);
+  ws.slow_list = (uint32_t*)(sp + SC_SLOW);
+  ws.retry2_list = (uint32_t*)(sp + SC_RETRY2);
+  ws.cap_slots = (uint32_t)NOALLOC_ITEMS;
+  return ws;
+}
+
 int check_verify_args(const fa_ctx* ctx, int logn, size_t count, const void* keys, const uint8_t* msg, const uint64_t* msg_off,
                       uint32_t mlen, const uint8_t* sig, int norm_policy, const uint8_t* accept)
 {
@@ -929,6 +985,7 @@ const char* fa_strerror(int code)
     case FA_E_ALIGN: return "device arrays must be 4-byte aligned";
     case FA_E_INTERNAL: return "internal error";
     case FA_E_UNRESOLVED: return "items left unresolved by the device-side retry pass: verify them again with a synchronising call";
+    case FA_E_TOO_MANY: return "more items than the allocation-free entry point takes (FA_NOALLOC_MAX_ITEMS)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
@@ -959,6 +1016,7 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMalloc((void**)&ctx->d_unresolved, 256);
     if (!rc) rc = (int)hipMemset(ctx->d_unresolved, 0, 256);
     if (!rc) rc = (int)hipHostMalloc((void**)&ctx->h_word, 64, hipHostMallocDefault);
+    if (!rc) rc = scratch_address(device, &ctx->scratch);  // this device current (Guard above)
   }
   for (int t = 0; t < 2 && !rc; t++) try {
     const Tables tb = make_tables(9 + t);
@@ -975,6 +1033,10 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMemcpy(ctx->d_itwc[t], tb.invC.data(), cbytes, hipMemcpyHostToDevice);
   } catch (...) {  // std::bad_alloc while building the tables
     rc = FA_E_INTERNAL;
+  }
+  if (!rc) {  // resident workgroups per CU of the kernels the allocation-free entry point launches, asked now
+    (void)stride_grid(ctx, verify_kernel<9, false, false>, 1u);
+    (void)stride_grid(ctx, verify_kernel<10, false, false>, 1u);
   }
   if (rc) {
     fa_ctx_destroy(ctx);
@@ -1148,6 +1210,47 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   rc = logn == 9 ? verify_dev<9>(ctx, count, nullptr, B, s) : verify_dev<10>(ctx, count, nullptr, B, s);
   const int re = ws_end(ctx, s);
   return rc ? rc : re;
+}
+
+int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
+                               const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept,
+                               void* stream)
+{
+  int rc = check_verify_args(ctx, logn, count, pk, msg, msg_off, mlen, sig, norm_policy, accept);
+  if (rc || count == 0) return rc;
+  if (count > NOALLOC_ITEMS) return FA_E_TOO_MANY;
+  if (ctx->wire != FA_WIRE_REFERENCE) return FA_E_ARG;  // the specification wire format repacks keys into a buffer of the context
+  if (ctx->hash_blocks[logn - 9] > 17u) return FA_E_ARG;  // the scratch array holds 17 blocks per item
+  if (!aligned4(pk) || !aligned4(sig) || !aligned4(msg) || ((uintptr_t)msg_off & 7u)) return FA_E_ALIGN;
+  if (!ctx->scratch) return FA_E_INTERNAL;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = ws_begin(ctx, s))) return rc;
+  const Workspace ws = ws_from_scratch(ctx->scratch);  // the device address, not the symbol
+  Batch B;
+  B.keys.pk = Rows{ pk, nullptr, (uint32_t)fa_pkey_len(logn) };
+  B.sig = Rows{ sig, nullptr, (uint32_t)fa_sig_len(logn) };
+  B.msg = msg;
+  B.msg_off = msg_off;
+  B.mlen = mlen;
+  B.policy = norm_policy;
+  B.accept = accept;
+  ctx->quiet = true;  // no profiling events, no second stream: nothing below allocates
+  if (logn == 9) {
+    rc = verify_enqueue<9>(ctx, ws, count, nullptr, B, s);
+    if (!rc) rc = retry_tail<9>(ctx, ws, B, s);
+  } else {
+    rc = verify_enqueue<10>(ctx, ws, count, nullptr, B, s);
+    if (!rc) rc = retry_tail<10>(ctx, ws, B, s);
+  }
+  ctx->quiet = false;
+  if (!rc) rc = (int)hipMemcpyAsync(ctx->h_word, ws.ctl + CTL_UNRESOLVED, 4, hipMemcpyDeviceToHost, s);  // into pinned memory of the context
+  const int re = ws_end(ctx, s);
+  if (!rc) rc = re;
+  if (!rc) rc = (int)hipStreamSynchronize(s);
+  if (rc) return rc;
+  return *ctx->h_word ? FA_E_UNRESOLVED : 0;
 }
 
 int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, const uint32_t* key_idx,

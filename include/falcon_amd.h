@@ -31,6 +31,7 @@ extern "C" {
 #define FA_E_ALIGN (-3)     /* a device array is not 4-byte aligned */
 #define FA_E_INTERNAL (-4)
 #define FA_E_UNRESOLVED (-5) /* asynchronous / allocation-free calls: items the device-side retry pass could not settle (see fa_finish) */
+#define FA_E_TOO_MANY (-6)   /* fa_verify_many_dev_noalloc: count > FA_NOALLOC_MAX_ITEMS */
 
 /* Longest message any entry point takes: the hash kernel counts the bytes of salt || message in 32-bit signed
  * integers (the reference takes a size_t mlen, hashing.hpp:16-21). Host entry points return FA_E_ARG beyond it; with
@@ -133,6 +134,21 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
  * FA_E_UNRESOLVED with the count in *unresolved (nullable) -- verify those batches again synchronously. No reference
  * counterpart: the reference is synchronous by nature. */
 int fa_finish(fa_ctx* ctx, void* stream, uint64_t* unresolved);
+
+/* The same as fa_verify_many_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): NO COUNTERPART IN THE REFERENCE. The pipeline's workspace is a
+ * static device array of the library (about 18 MB, held by every GPU the library runs on until the process ends)
+ * instead of buffers of the context, so the call makes no hipMalloc / hipFree and uses no allocating routine.
+ * Limits: count <= FA_NOALLOC_MAX_ITEMS (else FA_E_TOO_MANY); reference wire format; at most 17 hash blocks per
+ * item; no debug outputs. Items short of SHAKE256 blocks are settled by the device-side retry pass described at
+ * fa_finish; the call synchronises `stream` once and returns FA_E_UNRESOLVED if any item is left (probability
+ * ~1e-50 per item). All calls on one GPU -- from any context -- share that GPU's array, which keeps the previous
+ * call's contents (every call clears the counters it needs): calls that overlap on one GPU race; calls through one
+ * context are ordered by the library as described above. */
+#define FA_NOALLOC_MAX_ITEMS 4096
+int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
+                               const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
+                               uint8_t* accept, void* stream);
 
 /* ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
  * For callers that keep public keys decoded and verify many signatures per key (falcon.hpp:226-229,
