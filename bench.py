@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- Falcon-512 batched verify throughput on MI355X (BASELINE.json config 3).
+"""bench.py -- batched Falcon verify throughput on MI355X (BASELINE.json configs[2] by default).
 
-A step = one pass of the verify hot path (fa_verify_many_dev: decode -> SHAKE256 -> NTT/norm
-kernels) over one batch of 2^20 distinct (public key, 32-byte message, signature) triples that
-are already resident in HBM. With --gpus N > 1 every rank verifies its own 2^20-item shard
-(independent items, no collective on the data path: "weak" scaling); rank 0 prints ONE JSON line.
+A step = one pass of the verify hot path (decode -> SHAKE256 -> NTT/norm kernels) over one batch of distinct
+(public key, 32-byte message, signature) triples that are already resident in HBM:
 
-Extra legs on rank 0 at N == 1 (outside the timed region):
-  * cpu_baseline: the CPU oracle ("port" of the reference's falcon::verify<N>) over a bounded
-    sample of the same corpus with pthreads, plus an item-by-item comparison of the accept
-    flags with the GPU's;
-  * extras: Falcon-1024 with the malformed mix (config 4) and the n=512 batched polymul
-    (config 2) at reduced batch sizes, one timed pass each.
+  --workload falcon512   2^20 Falcon-512 triples per GPU, all valid            (configs[2]; the headline, default)
+  --workload falcon1024  2^20 Falcon-1024 triples per GPU, 25 % malformed mix  (configs[3])
+  --workload mixed       2^23 items per GPU, 50/50 Falcon-512 / Falcon-1024, tiled on the device from the two
+                         corpora above and verified in place by fa_verify_mixed_dev  (configs[4]: one GPU's share of
+                         the 64M-item batch; with --gpus 8 the whole of it)
+
+With --gpus N > 1 every rank verifies its own shard (independent items, no collective on the data path: "weak"
+scaling); rank 0 prints ONE JSON line.
+
+Extra legs on rank 0 at N == 1 (outside the timed region): cpu_baseline (the CPU oracle, a port of the reference's
+falcon::verify<N>, over a bounded sample of the same corpus with pthreads, plus an item-by-item comparison of the accept
+flags with the GPU's) and `extras` (the other BASELINE configs, the prepared-key path against the packed path in
+interleaved rounds, the host-buffer entry points).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -26,21 +30,49 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# Algorithmic work per unit, SURVEY.md section 8(d) (reference op-cost model, int32 lane-ops):
-#   Keccak-f[1600] = 7,440; butterfly = 11; pointwise modmul = 5; rejection sampling = 4 per draw;
-#   pk unpack = 3 and norm = 3 per coefficient; signature decode = 10 per coefficient.
-OPS_512 = {
-    "hash_kernel": 8.593 * 7440,
-    "verify_kernel": 9216 * 11 + 1024 * 5 + 546 * 4 + 512 * 3 + 512 * 3,
-    "decode_kernel": 512 * 10,
+# ---- work per unit -------------------------------------------------------------------------------------------------
+# ALG_OPS: the minimum number of 32-bit vector lane-operations one item needs in each kernel, counted at the cost the
+# kernels actually issue: a butterfly is 5 (3-instruction Shoup product, add, subtract), three
+# transforms per verify (two forward, one inverse); a Keccak-f[1600] round on 32-bit halves is 180 (theta 80, rho/pi 48,
+# chi 50, iota 2) and an item needs 8.593 permutations on average (the kernel runs 9 for every item);
+# signature decoding 10 per coefficient. By construction these are <= what the kernels issue, so achieved / peak <= 1.
+# REF_OPS is SURVEY.md 8(d)'s model of the REFERENCE's work (11 per butterfly, 4 transforms), reported beside it only.
+ALG_OPS = {
+    9: {"verify_kernel": 3 * 2304 * 5 + 512 * 5 + 512 * 2 + 512 * 6 + 612 * 3,
+        "hash_kernel": 8.593 * 24 * 180,
+        "decode_kernel": 512 * 10},
+    10: {"verify_kernel": 3 * 5120 * 5 + 1024 * 5 + 1024 * 2 + 1024 * 6 + 1224 * 3,
+         "hash_kernel": 16.7 * 24 * 180,
+         "decode_kernel": 1024 * 10},
 }
-BYTES_512 = 897 + 666 + 32 + 1   # compulsory HBM bytes per verify
-PEAK_VALU_TIOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+REF_OPS_512 = {"hash_kernel": 8.593 * 7440, "verify_kernel": 9216 * 11 + 1024 * 5 + 546 * 4 + 512 * 3 + 512 * 3,
+               "decode_kernel": 512 * 10}
+POLYMUL_OPS_512 = 3 * 2304 * 5 + 512 * 9 + 512 * 2   # transforms, pointwise (two reductions + product), final reduction
+BYTES = {9: 897 + 666 + 32 + 1, 10: 1793 + 1280 + 32 + 1}   # compulsory HBM bytes per verify
+PEAK_VALU_TIOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (full-rate instructions)
 PEAK_HBM_GBS = 8000.0
+PMC_SOURCE = os.path.join("profiles", "hbm_traffic.json")   # counters of the same launch shape, collected by tools/profile_all.sh
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Host cores this process may use: the smaller of the machine's count, the affinity mask and the job's share
+    (the GPU boxes export it as OMP_NUM_THREADS; os.cpu_count() there is the whole machine, many jobs' worth)."""
+    n = os.cpu_count() or 1
+    src = "os.cpu_count()"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, src = a, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and 0 < int(share) < n:
+        n, src = int(share), "the job's CPU share (OMP_NUM_THREADS)"
+    return n, src
 
 
 def main():
@@ -48,12 +80,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--items", type=int, default=1 << 20, help="items per GPU per step")
+    ap.add_argument("--workload", default="", choices=("", "falcon512", "falcon1024", "mixed"))
+    ap.add_argument("--items", type=int, default=0, help="items per GPU per step (default 2^20; mixed: 2^23)")
     ap.add_argument("--chunk", type=int, default=0, help="override FA_OPT_CHUNK_ITEMS")
     ap.add_argument("--cpu-sample", type=int, default=1 << 18)
-    ap.add_argument("--logn", type=int, default=9, choices=(9, 10),
-                    help="9 = Falcon-512 (the headline workload, BASELINE.json configs[2]); 10 = Falcon-1024 (A/B runs only)")
-    ap.add_argument("--malformed", type=int, default=0, help="permille of malformed items in the timed corpus (A/B runs only)")
+    ap.add_argument("--logn", type=int, default=9, choices=(9, 10), help="older spelling of --workload falcon512 / falcon1024")
+    ap.add_argument("--malformed", type=int, default=-1, help="permille of malformed items in the timed corpus (A/B runs only)")
     ap.add_argument("--overlap", type=int, default=-1, help="override FA_OPT_OVERLAP (A/B runs only)")
     ap.add_argument("--grid-per-cu", type=int, default=-1, help="override FA_OPT_GRID_PER_CU (A/B runs only)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -63,6 +95,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    workload = args.workload or ("falcon512" if args.logn == 9 else "falcon1024")
+    mixed = workload == "mixed"
+    logn = 10 if workload == "falcon1024" else 9
+    malformed = args.malformed if args.malformed >= 0 else (250 if workload == "falcon1024" and args.workload else 0)
 
     import torch
     import torch.distributed as dist
@@ -83,11 +119,12 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    import falcon_amd
+    import falcon_amd  # noqa: F401
     from falcon_amd import capi
+    import mixed_batch
     import support
 
-    threads = max(1, min(os.cpu_count() or 1, 16))
+    threads, threads_src = host_cores()
     ctx = capi.Context(local_rank)
     if args.chunk:
         ctx.set_option(capi.OPT_CHUNK_ITEMS, args.chunk)
@@ -95,28 +132,76 @@ def main():
         ctx.set_option(capi.OPT_OVERLAP, args.overlap)
     if args.grid_per_cu >= 0:
         ctx.set_option(capi.OPT_GRID_PER_CU, args.grid_per_cu)
-
-    # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
-    n_items = args.items
-    t0 = time.time()
-    logn = args.logn
-    pk, msg, sig, _ = support.corpus().generate(logn, n_items, seed=0xFA1C0512, first=rank * n_items, mlen=32,
-                                                malformed_permille=args.malformed, threads=threads)
-    log(f"[rank {rank}] corpus: {n_items} Falcon-{1 << logn} triples in {time.time() - t0:.1f}s ({threads} threads)")
-    d_pk = torch.from_numpy(pk).to(dev)
-    d_msg = torch.from_numpy(np.ascontiguousarray(msg)).to(dev)
-    d_sig = torch.from_numpy(sig).to(dev)
-    d_acc = torch.zeros(n_items, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        ctx.verify_many_dev(logn, n_items, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
-                            d_acc.data_ptr(), stream=stream)
+    def upload(*arrs):
+        return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+    def build_mixed(c9, c10, n_items, seed):
+        """2 * npairs items on the device: the two class corpora (torch tensors pk, msg, sig) tiled and interleaved
+        pair by pair (tests/mixed_batch.py). Returns the tensors fa_verify_mixed_dev takes."""
+        base = c9[0].shape[0]
+        npairs = n_items // 2
+        tile = max(1, npairs // base)
+        npairs = base * tile if npairs >= base else npairs
+        if npairs < base:
+            c9 = [t[:npairs] for t in c9]
+            c10 = [t[:npairs] for t in c10]
+        bits = mixed_batch.pair_order_bits(npairs, seed)
+        tags, pk_off, sig_off, msg_off, _ = mixed_batch.layout(bits, 32)
+        bits_t = torch.from_numpy(bits).to(dev)
+        d = {"count": 2 * npairs,
+             "logn": torch.from_numpy(tags).to(dev),
+             "pk": mixed_batch.pack_torch(bits_t, c9[0], c10[0], tile if npairs >= base else 1),
+             "msg": mixed_batch.pack_torch(bits_t, c9[1], c10[1], tile if npairs >= base else 1),
+             "sig": mixed_batch.pack_torch(bits_t, c9[2], c10[2], tile if npairs >= base else 1),
+             "pk_off": torch.from_numpy(pk_off.view(np.int64)).to(dev),
+             "sig_off": torch.from_numpy(sig_off.view(np.int64)).to(dev),
+             "msg_off": torch.from_numpy(msg_off.view(np.int64)).to(dev)}
+        d["accept"] = torch.zeros(d["count"], dtype=torch.uint8, device=dev)
+        return d, bits
+
+    def run_mixed(d):
+        ctx.verify_mixed_dev(d["count"], d["logn"].data_ptr(), d["pk"].data_ptr(), d["pk_off"].data_ptr(), d["msg"].data_ptr(),
+                             d["msg_off"].data_ptr(), d["sig"].data_ptr(), d["sig_off"].data_ptr(), d["accept"].data_ptr(),
+                             stream=stream)
+
+    # ---- corpus: this rank's shard of the seeded stream (counter-based, corpus/falcon_corpus.c) ----
+    t0 = time.time()
+    if mixed:
+        n_items = args.items or (1 << 23)
+        base = min(1 << 20, n_items // 2)
+        c9h = support.corpus().generate(9, base, seed=0xFA1C0512, first=rank * base, mlen=32, threads=threads)
+        c10h = support.corpus().generate(10, base, seed=0xFA1C1024, first=rank * base, mlen=32, malformed_permille=250, threads=threads)
+        c9, c10 = upload(*c9h[:3]), upload(*c10h[:3])
+        mx, mx_bits = build_mixed(c9, c10, n_items, 0x5EED + rank)
+        n_items = mx["count"]
+        del c9, c10
+        torch.cuda.empty_cache()
+        log(f"[rank {rank}] corpus: {n_items} mixed items ({base} distinct triples per class, tiled on the device) in {time.time() - t0:.1f}s")
+
+        def step():
+            run_mixed(mx)
+        d_acc = mx["accept"]
+    else:
+        n_items = args.items or (1 << 20)
+        pk, msg, sig, kinds = support.corpus().generate(logn, n_items, seed=0xFA1C0512 if logn == 9 else 0xFA1C1024, first=rank * n_items,
+                                                        mlen=32, malformed_permille=malformed, threads=threads)
+        log(f"[rank {rank}] corpus: {n_items} Falcon-{1 << logn} triples in {time.time() - t0:.1f}s ({threads} threads)")
+        d_pk, d_msg, d_sig = upload(pk, msg, sig)
+        d_acc = torch.zeros(n_items, dtype=torch.uint8, device=dev)
+
+        def step():
+            ctx.verify_many_dev(logn, n_items, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
+                                d_acc.data_ptr(), stream=stream)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    ctx.set_option(capi.OPT_PROFILE, 1)   # HIP events around every kernel, on the launch stream
+    # HIP events around every kernel, on the launch stream, taken from a pool that the warm-up pass below fills: the
+    # timed loop creates no events, it records two per kernel launch
+    ctx.set_option(capi.OPT_PROFILE, 1)
+    step()
     ctx.get_profile()
     if world > 1:
         dist.barrier()
@@ -141,13 +226,19 @@ def main():
 
     total_items = n_items * world * args.steps
     value = total_items / elapsed
+    names = {"falcon512": ("Falcon-512 verifies/sec", f"Falcon-512 batched verify, {n_items} distinct keys/signatures per GPU, 32-byte messages, "
+                           "device-resident (BASELINE.json configs[2])"),
+             "falcon1024": ("Falcon-1024 verifies/sec", f"Falcon-1024 batched verify, {n_items} distinct keys/signatures per GPU, 32-byte messages, "
+                            "device-resident (BASELINE.json configs[3])"),
+             "mixed": ("Falcon-512/1024 verifies/sec", f"mixed Falcon-512 + Falcon-1024 batch, {n_items} items per GPU, 50/50 by N, the Falcon-1024 half "
+                       "with the 25 % malformed mix, tiled on the device from 2^20-item corpora, verified in place by fa_verify_mixed_dev "
+                       f"(BASELINE.json configs[4]: {n_items * world} items over {world} GPU(s))")}
     result = {
-        "metric": f"Falcon-{1 << logn} verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
+        "metric": names[workload][0], "value": value, "unit": "verifies/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (mod q = 12289), u64 Keccak lanes",
         "data": "synthetic",
-        "config": {"workload": f"Falcon-{1 << logn} batched verify, {n_items} distinct keys/signatures per GPU, 32-byte messages, "
-                               f"device-resident (BASELINE.json configs[{logn - 7}])" + (f", {args.malformed} permille malformed" if args.malformed else ""),
+        "config": {"workload": names[workload][1] + (f", {malformed} permille malformed" if malformed and not mixed else ""),
                    "items_per_gpu": n_items, "parallelism": f"items sharded over {world} GPU(s), no collective"},
         "accepted_fraction": accepted / (n_items * world),
     }
@@ -158,44 +249,71 @@ def main():
         kern_n = {"hash_kernel": prof["launches_hash"], "verify_kernel": prof["launches_verify"],
                   "decode_kernel": prof["launches_decode"]}
         dom = max(kern_ms, key=kern_ms.get)
-        items_per_launch = n_items * args.steps / max(kern_n[dom], 1)
         avg_ms = kern_ms[dom] / max(kern_n[dom], 1)
-        achieved = OPS_512[dom] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, issued = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                counters = json.load(open(tpath))
-                traffic = counters.get(dom)
-                issued = counters.get("valu_instructions_per_launch", {}).get(dom)
-            except Exception:
-                traffic, issued = None, None
-        result["roofline"] = {
+        if mixed:   # two launches per kernel and step (one per class): ops and bytes of an average launch
+            items_per_launch = n_items * args.steps / max(kern_n[dom], 1)
+            ops_item = 0.5 * (ALG_OPS[9][dom] + ALG_OPS[10][dom])
+            bytes_item = 0.5 * (BYTES[9] + BYTES[10])
+        else:
+            items_per_launch = n_items * args.steps / max(kern_n[dom], 1)
+            ops_item, bytes_item = ALG_OPS[logn][dom], BYTES[logn]
+        achieved = ops_item * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        roof = {
             "bound": "valu", "kernel": dom, "achieved": achieved, "peak": PEAK_VALU_TIOPS, "unit": "Tiop/s",
-            "frac": achieved / PEAK_VALU_TIOPS, "traffic": traffic,
-            "avg_launch_ms": avg_ms, "items_per_launch": items_per_launch, "algorithmic_ops_per_item": OPS_512[dom],
-            "note": "integer VALU work, no MFMA; peak = 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s (SURVEY.md 8d). achieved counts the "
-                    "reference's operations (11 per butterfly, 4 transforms); the kernel issues 5 per butterfly and runs 3 "
-                    "transforms, so frac can pass 1 -- issue_utilisation is the share of the vector issue slots in use",
+            "frac": achieved / PEAK_VALU_TIOPS, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches_timed": kern_n[dom], "items_per_launch": items_per_launch,
+            "algorithmic_ops_per_item": ops_item,
+            "note": "integer VALU work, no MFMA. achieved = minimum lane-operations of this kernel's work at the issued cost (bench.py "
+                    "ALG_OPS: 5 per butterfly, 3 transforms; 180 per Keccak round) x items per launch / average launch time measured with "
+                    "HIP events in this run; peak = 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s, which only full-rate instructions reach "
+                    "(multiplies, mad, bitop3, alignbit issue at half rate: DESIGN.md section 6)",
         }
-        if issued and avg_ms > 0 and logn == 9 and n_items == 1 << 20 and not args.malformed:
-            # wave instructions of this kernel per launch (PMC, profiles/) x 4 cycles per issue slot / (SIMDs x clock x time)
-            result["roofline"]["issue_utilisation"] = issued * 4 / (1024 * 2.4e9 * avg_ms * 1e-3)
-            result["roofline"]["issued_valu_instructions"] = issued
+        if workload == "falcon512":
+            roof["reference_op_model"] = {"ops_per_item": REF_OPS_512[dom],
+                                          "rate_Tiops": REF_OPS_512[dom] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                                          "note": "SURVEY.md 8(d) cost model of the REFERENCE's operations (11 per butterfly, 4 transforms); "
+                                                  "not a roofline fraction: the kernel does the same work in fewer instructions"}
+        tpath = os.path.join(ROOT, PMC_SOURCE)
+        if workload == "falcon512" and n_items == 1 << 20 and os.path.exists(tpath):
+            try:   # counters of the same launch (2^20 Falcon-512 items), collected in separate rocprofv3 --pmc passes
+                counters = json.load(open(tpath))
+                roof["traffic"] = counters["hbm_bytes_per_launch"][dom]
+                issued = counters["valu_instructions_per_launch"][dom]
+                clock = counters.get("clock_ghz", {}).get(dom)
+                roof["pmc"] = {"source": PMC_SOURCE + " (" + counters.get("_from", "?") + ")",
+                               "issued_valu_wave_instructions": issued,
+                               "issued_lane_ops_frac_of_peak": issued * 64 / (avg_ms * 1e-3) / 1e12 / PEAK_VALU_TIOPS,
+                               "clock_ghz_from_GRBM_GUI_ACTIVE": clock,
+                               "cycles_per_valu_instruction_per_simd": (clock * 1e9 * avg_ms * 1e-3 * 1024 / issued) if clock else None}
+            except Exception as e:   # the profile is optional
+                log("no PMC summary:", e)
+        result["roofline"] = roof
         result["kernels_ms_per_step"] = {k: v / args.steps for k, v in kern_ms.items()}
         per_gpu_rate = n_items * args.steps / elapsed
-        # the same launch against the HBM roofline, in the contract's form: SURVEY.md 8(d)'s compulsory bytes per
-        # verify x the items one launch processes / that kernel's average launch time; traffic = measured HBM bytes
-        # of that launch (PMC, profiles/hbm_traffic.json). Far from the bound: the path is VALU-issue limited.
-        hbm_achieved = BYTES_512 * items_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        hbm_achieved = bytes_item * items_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": hbm_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": hbm_achieved / PEAK_HBM_GBS, "traffic": traffic,
-                                  "algorithmic_bytes_per_item": BYTES_512,
-                                  "whole_path_GBps": per_gpu_rate * BYTES_512 / 1e9}
-        result["whole_path_valu_frac"] = per_gpu_rate * sum(OPS_512.values()) / 1e12 / PEAK_VALU_TIOPS
+                                  "frac": hbm_achieved / PEAK_HBM_GBS, "traffic": roof["traffic"],
+                                  "algorithmic_bytes_per_item": bytes_item,
+                                  "whole_path_GBps": per_gpu_rate * bytes_item / 1e9}
+        ops_all = sum(ALG_OPS[logn].values()) if not mixed else 0.5 * (sum(ALG_OPS[9].values()) + sum(ALG_OPS[10].values()))
+        result["whole_path_valu_frac"] = per_gpu_rate * ops_all / 1e12 / PEAK_VALU_TIOPS
         result["retried_items"] = prof["retried_items"]
 
-    if rank == 0 and world == 1 and not args.no_cpu:
+    def timeit(fn, reps=5, warm=2):
+        """Median and minimum time of `reps` calls of fn (each synchronised), after `warm` untimed calls."""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], ts[0]
+
+    if rank == 0 and world == 1 and not args.no_cpu and not mixed:
         # ---- CPU baseline: the oracle over a bounded sample of the same corpus ----
         ns = min(args.cpu_sample, n_items)
         orc = support.oracle()
@@ -213,54 +331,71 @@ def main():
         gpu_flags = d_acc.cpu().numpy()
         result["cpu_baseline"] = {
             "value": ns / dt, "unit": "verifies/s", "cores": threads, "kind": "port",
-            "sample": f"first {ns} items of the same corpus, one verify per item, {threads} pthreads "
-                      f"(~{dt * threads:.0f} core-seconds; oracle/falcon_oracle.c, gcc -O3 -std=c11); "
+            "sample": f"first {ns} items of the same corpus, one verify per item, {threads} pthreads = {threads_src} "
+                      f"(machine: {os.cpu_count()} CPUs; ~{dt * threads:.0f} core-seconds; oracle/falcon_oracle.c, gcc -O3 -std=c11); "
                       f"single thread: {1e6 * dt1 / n1:.1f} us/verify",
-            "single_thread_us": 1e6 * dt1 / n1,
+            "host_cpus": os.cpu_count(), "single_thread_us": 1e6 * dt1 / n1,
             "accept_flags_compared": int(flags.size),
             "accept_mismatches_vs_gpu": int((gpu_flags != (flags & 1)).sum()),
         }
+    elif rank == 0 and world == 1 and not args.no_cpu and mixed:
+        # mixed workload: the oracle over a bounded sample of the first pairs (both classes), flags compared item by item
+        ns = min(args.cpu_sample // 4, c9h[0].shape[0])
+        orc = support.oracle()
+        t0 = time.perf_counter()
+        f9, _ = orc.verify_many(9, c9h[0][:ns], c9h[1][:ns], c9h[2][:ns], threads=threads)
+        f10, _ = orc.verify_many(10, c10h[0][:ns], c10h[1][:ns], c10h[2][:ns], threads=threads)
+        dt = time.perf_counter() - t0
+        tags = mx["logn"][:2 * ns].cpu().numpy()
+        src = np.repeat(np.arange(ns), 2)
+        want = np.where(tags == 9, f9[src], f10[src]) & 1
+        got = d_acc[:2 * ns].cpu().numpy()
+        result["cpu_baseline"] = {
+            "value": 2 * ns / dt, "unit": "verifies/s", "cores": threads, "kind": "port",
+            "sample": f"the first {ns} pairs of the batch (one Falcon-512 and one Falcon-1024 verify each), {threads} pthreads = {threads_src} "
+                      f"(machine: {os.cpu_count()} CPUs; oracle/falcon_oracle.c, gcc -O3 -std=c11)",
+            "host_cpus": os.cpu_count(), "accept_flags_compared": int(want.size),
+            "accept_mismatches_vs_gpu": int((got != want).sum()),
+        }
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and workload == "falcon512":
         extras = {}
         # Falcon-1024 with the malformed mix (BASELINE.json configs[3]) at its full 2^20 items
         ne = min(n_items, 1 << 20)
-        pk2, msg2, sig2, kinds = support.corpus().generate(10, ne, seed=0xFA1C1024, mlen=32, malformed_permille=250,
-                                                           threads=threads)
-        e_pk, e_msg, e_sig = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (pk2, msg2, sig2))
+        pk2, msg2, sig2, kinds2 = support.corpus().generate(10, ne, seed=0xFA1C1024, mlen=32, malformed_permille=250, threads=threads)
+        e_pk, e_msg, e_sig = upload(pk2, msg2, sig2)
         e_acc = torch.zeros(ne, dtype=torch.uint8, device=dev)
 
         def step1024():
             ctx.verify_many_dev(10, ne, e_pk.data_ptr(), e_msg.data_ptr(), None, 32, e_sig.data_ptr(),
                                 e_acc.data_ptr(), stream=stream)
-        step1024()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            step1024()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
+        med, best = timeit(step1024, reps=7, warm=3)
         nchk = 1 << 14
         oflags, _ = support.oracle().verify_many(10, pk2[:nchk], msg2[:nchk], sig2[:nchk], threads=threads)
         extras["falcon1024_malformed_mix"] = {
-            "verifies_per_s": ne / dt, "items": ne, "malformed_share": float((kinds != 0).mean()),
+            "verifies_per_s": ne / med, "best": ne / best, "items": ne, "malformed_share": float((kinds2 != 0).mean()),
             "accepted_fraction": float(e_acc.float().mean().item()),
             "accept_mismatches_vs_oracle_first_16384": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum())}
-        # mixed Falcon-512 + Falcon-1024 batch (BASELINE.json configs[4], one GPU's share): the batch is split by N
-        # and runs as one pass per class; `ne` items of each class here
-        if logn == 9:
-            def step_mixed():
-                ctx.verify_many_dev(9, ne, d_pk.data_ptr(), d_msg.data_ptr(), None, 32, d_sig.data_ptr(),
-                                    d_acc.data_ptr(), stream=stream)
-                step1024()
-            step_mixed()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                step_mixed()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 3
-            extras["mixed_512_1024"] = {"verifies_per_s": 2 * ne / dt, "items": 2 * ne, "share_1024": 0.5}
+        rate1024 = ne / med
+        # mixed Falcon-512 + Falcon-1024 batch (BASELINE.json configs[4]): ONE GPU's share of the 64M-item batch, 2^23 items,
+        # tiled on the device from the two 2^20-item corpora and verified in place by fa_verify_mixed_dev
+        if n_items == 1 << 20:
+            mx, _ = build_mixed([d_pk, d_msg, d_sig], [e_pk, e_msg, e_sig], 1 << 23, 0x5EED)
+            med, best = timeit(lambda: run_mixed(mx), reps=5, warm=2)
+            rate512 = value
+            harm = 2.0 / (1.0 / rate512 + 1.0 / rate1024)
+            got = mx["accept"][:1 << 15].cpu().numpy()
+            tags = mx["logn"][:1 << 15].cpu().numpy()
+            f9 = d_acc[:1 << 14].cpu().numpy()
+            f10 = e_acc[:1 << 14].cpu().numpy()
+            src = np.repeat(np.arange(1 << 14), 2)
+            extras["mixed_512_1024_config5_share"] = {
+                "verifies_per_s": mx["count"] / med, "best": mx["count"] / best, "items": mx["count"], "share_1024": 0.5,
+                "harmonic_mean_of_single_class_rates": harm, "ratio_to_harmonic_mean": mx["count"] / med / harm,
+                "accept_mismatches_vs_single_class_paths_first_32768": int((got != np.where(tags == 9, f9[src], f10[src])).sum()),
+                "accepted_fraction": float(mx["accept"].float().mean().item())}
+            del mx
+            torch.cuda.empty_cache()
         del e_pk, e_msg, e_sig, e_acc
         # host-buffer entry point (fa_verify_many: H2D staging + kernels + D2H), pageable numpy memory: the
         # PCIe-inclusive rate that DESIGN.md section 7 quotes; never the headline value
@@ -285,42 +420,58 @@ def main():
                                                         "accepted_fraction": float(pin[3].array.mean())}
         for b in pin:
             b.close()
-        # decoded-key fast path: keys prepared once (NTT(h) resident), same 2^20 Falcon-512 items
-        if logn == 9:
-            d_prep = torch.empty((n_items, 512), dtype=torch.int16, device=dev)
-            t0 = time.perf_counter()
-            ctx.prepare_keys_dev(9, n_items, d_pk.data_ptr(), None, d_prep.data_ptr(), stream=stream)
-            torch.cuda.synchronize()
-            t_prep = time.perf_counter() - t0
-            p_acc = torch.zeros(n_items, dtype=torch.uint8, device=dev)
-
-            def step_prepared():
-                ctx.verify_many_prepared_dev(9, n_items, d_prep.data_ptr(), None, d_msg.data_ptr(), None, 32,
-                                             d_sig.data_ptr(), p_acc.data_ptr(), stream=stream)
-            step_prepared()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                step_prepared()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 3
-            extras["falcon512_prepared_keys"] = {"verifies_per_s": n_items / dt, "items": n_items,
-                                                 "prepare_keys_per_s": n_items / t_prep,
-                                                 "accept_mismatches_vs_packed_path": int((p_acc != d_acc).sum().item())}
-            del d_prep, p_acc
-        # batched negacyclic polymul, n = 512 (BASELINE.json configs[1]) at 2^22 polynomials per operand
-        npoly = 1 << 22
-        a = torch.randint(0, 12289, (npoly, 512), dtype=torch.int32, device=dev).to(torch.int16)
-        b = torch.randint(0, 12289, (npoly, 512), dtype=torch.int32, device=dev).to(torch.int16)
-        c = torch.empty_like(a)
-        ctx.polymul_many_dev(9, npoly, a.data_ptr(), b.data_ptr(), c.data_ptr(), stream=stream)
+        # decoded-key fast path: keys prepared once (NTT(h) resident), same 2^20 Falcon-512 items, against the
+        # packed-key path in interleaved rounds of one process (the GPU's clock drifts with load: back-to-back legs are not
+        # comparable, alternating rounds are)
+        d_prep = torch.empty((n_items, 512), dtype=torch.int16, device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(3):
-            ctx.polymul_many_dev(9, npoly, a.data_ptr(), b.data_ptr(), c.data_ptr(), stream=stream)
+        ctx.prepare_keys_dev(9, n_items, d_pk.data_ptr(), None, d_prep.data_ptr(), stream=stream)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        extras["polymul_n512"] = {"polys_per_s": npoly / dt, "polys": npoly, "hbm_GBps": npoly * 3072 / dt / 1e9}
+        t_prep = time.perf_counter() - t0
+        p_acc = torch.zeros(n_items, dtype=torch.uint8, device=dev)
+
+        def step_prepared():
+            ctx.verify_many_prepared_dev(9, n_items, d_prep.data_ptr(), None, d_msg.data_ptr(), None, 32,
+                                         d_sig.data_ptr(), p_acc.data_ptr(), stream=stream)
+        for _ in range(3):
+            step()
+            step_prepared()
+        torch.cuda.synchronize()
+        tp, tk = [], []
+        for _ in range(8):
+            for fn, acc_t in ((step, tk), (step_prepared, tp)):
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                acc_t.append((time.perf_counter() - t0) / 3)
+        tp.sort()
+        tk.sort()
+        extras["falcon512_prepared_keys"] = {"verifies_per_s": n_items / tp[len(tp) // 2], "items": n_items,
+                                             "packed_path_same_rounds_verifies_per_s": n_items / tk[len(tk) // 2],
+                                             "gain_over_packed_path": tk[len(tk) // 2] / tp[len(tp) // 2],
+                                             "rounds": "8 interleaved rounds of 3 steps each, medians",
+                                             "prepare_keys_per_s": n_items / t_prep,
+                                             "accept_mismatches_vs_packed_path": int((p_acc != d_acc).sum().item())}
+        del d_prep, p_acc
+        # batched negacyclic polymul, n = 512 (BASELINE.json configs[1]) at its full 2^24 polynomials per operand
+        # (3 x 16 GiB resident), with its own roofline entries
+        npoly = 1 << 24
+        a = torch.empty((npoly, 512), dtype=torch.int16, device=dev)
+        b = torch.empty((npoly, 512), dtype=torch.int16, device=dev)
+        for c0 in range(0, npoly, 1 << 21):
+            a[c0:c0 + (1 << 21)] = torch.randint(0, 12289, (1 << 21, 512), dtype=torch.int16, device=dev)
+            b[c0:c0 + (1 << 21)] = torch.randint(0, 12289, (1 << 21, 512), dtype=torch.int16, device=dev)
+        c = torch.empty_like(a)
+        med, best = timeit(lambda: ctx.polymul_many_dev(9, npoly, a.data_ptr(), b.data_ptr(), c.data_ptr(), stream=stream), reps=5, warm=2)
+        extras["polymul_n512"] = {"polys_per_s": npoly / med, "best": npoly / best, "polys": npoly,
+                                  "roofline": {"bound": "valu", "kernel": "polymul_kernel", "achieved": npoly / med * POLYMUL_OPS_512 / 1e12,
+                                               "peak": PEAK_VALU_TIOPS, "unit": "Tiop/s", "frac": npoly / med * POLYMUL_OPS_512 / 1e12 / PEAK_VALU_TIOPS,
+                                               "algorithmic_ops_per_item": POLYMUL_OPS_512},
+                                  "roofline_hbm": {"bound": "hbm", "achieved": npoly / med * 3072 / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                   "frac": npoly / med * 3072 / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_item": 3072}}
+        del a, b, c
         result["extras"] = extras
 
     if rank == 0:

@@ -684,8 +684,12 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
     const uint32_t grid = stride_grid(ctx, kernel, want);
     return timed(ctx, s, 2, [&] { hipLaunchKernelGGL(kernel, dim3(grid), dim3(VERIFY_WG), 0, s, A); });
   };
-  if (B.keys.prepared) return B.debug ? launch(verify_kernel<LOGN, true, true>) : launch(verify_kernel<LOGN, false, true>);
-  return B.debug ? launch(verify_kernel<LOGN, true, false>) : launch(verify_kernel<LOGN, false, false>);
+  if (B.keys.pk.off || dcount) {  // the general instantiations: offset arrays, device-side count
+    if (B.keys.prepared) return B.debug ? launch(verify_kernel<LOGN, true, true, true>) : launch(verify_kernel<LOGN, false, true, true>);
+    return B.debug ? launch(verify_kernel<LOGN, true, false, true>) : launch(verify_kernel<LOGN, false, false, true>);
+  }
+  if (B.keys.prepared) return B.debug ? launch(verify_kernel<LOGN, true, true, false>) : launch(verify_kernel<LOGN, false, true, false>);
+  return B.debug ? launch(verify_kernel<LOGN, true, false, false>) : launch(verify_kernel<LOGN, false, false, false>);
 }
 
 void set_debug(Batch& B, const fa_debug* dbgp)
@@ -1035,8 +1039,10 @@ int fa_ctx_create(int device, fa_ctx** out)
     rc = FA_E_INTERNAL;
   }
   if (!rc) {  // resident workgroups per CU of the kernels the allocation-free entry point launches, asked now
-    (void)stride_grid(ctx, verify_kernel<9, false, false>, 1u);
-    (void)stride_grid(ctx, verify_kernel<10, false, false>, 1u);
+    (void)stride_grid(ctx, verify_kernel<9, false, false, false>, 1u);
+    (void)stride_grid(ctx, verify_kernel<10, false, false, false>, 1u);
+    (void)stride_grid(ctx, verify_kernel<9, false, false, true>, 1u);
+    (void)stride_grid(ctx, verify_kernel<10, false, false, true>, 1u);
   }
   if (rc) {
     fa_ctx_destroy(ctx);

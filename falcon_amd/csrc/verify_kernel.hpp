@@ -504,7 +504,7 @@ struct ItemRegs {
   uint32_t sqn, st, item, pal;
 };
 
-template <int LOGN, bool PREPARED>
+template <int LOGN, bool PREPARED, bool GENERAL>
 __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_t slot, uint32_t lane, ItemRegs<LOGN>& r)
 {
   using G = Geo<LOGN>;
@@ -550,7 +550,7 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   if constexpr (PREPARED) {
     r.pal = 0u;  // (the key row was requested first, above)
   } else {
-    const uint8_t* pkrow = A.pk.at(r.item);
+    const uint8_t* pkrow = GENERAL ? A.pk.at(r.item) : A.pk.base + (size_t)r.item * G::PKLEN;
     r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
     const uint32_t* pbase = (const uint32_t*)(pkrow - r.pal);
     const uint32_t last_dw = (r.pal + (uint32_t)G::PKLEN - 1u) >> 2;
@@ -567,7 +567,10 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
 // PREPARED: the public key arrives as NTT(h) (prepare_keys_kernel) instead of packed bytes -- the
 // decoded-key form of verification::verify<N, beta2>(h, ...) (verification.hpp:20-26, falcon.hpp:226-229) for
 // callers that verify many signatures per key: no unpacking and one forward transform less per item.
-template <int LOGN, bool DEBUG, bool PREPARED>
+// GENERAL: key records through A.pk's offset array and a device-side slot count (mixed batches, the device-side retry
+// pass). A template parameter rather than a run-time test because the two extra pointers cost the main instantiation its
+// fifth wave per SIMD (82 -> 101 VGPRs, scalar registers spilling to vector lanes: +11 % cycles, measured).
+template <int LOGN, bool DEBUG, bool PREPARED, bool GENERAL>
 __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN> A)
 {
   using G = Geo<LOGN>;
@@ -587,10 +590,10 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
 
   uint32_t slot = blockIdx.x * VERIFY_WAVES + wave;
-  const uint32_t count = A.dcount ? min(A.count, *A.dcount) : A.count;
+  const uint32_t count = GENERAL && A.dcount ? min(A.count, *A.dcount) : A.count;
   if (slot >= count) return;
   ItemRegs<LOGN> cur;
-  prefetch_item<LOGN, PREPARED>(A, slot, lane, cur);
+  prefetch_item<LOGN, PREPARED, GENERAL>(A, slot, lane, cur);
   // The first item's loads are waited for here, once, before the loop. Without this the loop header inherits
   // "loads into cur outstanding" from this path, hipcc's wait insertion cannot tell how many loads were issued
   // since, and every iteration waited for ALL memory operations (s_waitcnt vmcnt(0)) right after issuing the next
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
     const uint32_t nslot = slot + nwaves;
     const bool more = nslot < count;  // wave-uniform
     ItemRegs<LOGN> nxt;
-    if (more) prefetch_item<LOGN, PREPARED>(A, nslot, lane, nxt);
+    if (more) prefetch_item<LOGN, PREPARED, GENERAL>(A, nslot, lane, nxt);
 
     const uint32_t item = cur.item;
     // header byte of the key row = byte `pal` of aligned dword 0 (lane 0 holds it); falcon.hpp:240-243
