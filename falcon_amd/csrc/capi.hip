@@ -1056,7 +1056,13 @@ void fa_ctx_destroy(fa_ctx* ctx)
 {
   if (!ctx) return;
   Guard g(ctx->device);
-  (void)hipDeviceSynchronize();  // work enqueued on the caller's streams may still use the context's buffers
+  // Work enqueued on a caller's stream may still use the context's buffers: wait for the last use of the workspace and
+  // for the context's own streams. (Not hipDeviceSynchronize: contexts are also destroyed from thread-exit and static
+  // destructors, where a device-wide wait on a runtime that is shutting down does not return.)
+  if (ctx->ws_busy && ctx->ev_ws) (void)hipEventSynchronize(ctx->ev_ws);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+  if (ctx->copy) (void)hipStreamSynchronize(ctx->copy);
   for (auto& e : ctx->events) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);

@@ -5,6 +5,7 @@
 // reference tree):
 //
 //   falcon::verify<N>(pkey, msg, mlen, sig)            falcon.hpp:230-249   same signature, same bool
+//   falcon::verify<N>(h, msg, mlen, sig)               verification.hpp:20-26   one call with the key kept decoded
 //   falcon::verify_many<N>(count, pkeys, msgs, ...)    no counterpart: `count` independent calls of the above
 //   falcon::prepared_keys<N> + verify_many<N>(count, keys, key_idx, ...)
 //                                                      verification.hpp:20-26   verify with the key kept decoded
@@ -14,7 +15,12 @@
 //   falcon::decode_pkeys<N>(count, pkeys, h, ok)       decoding.hpp:18-48
 //   falcon::decode_sigs<N>(count, sigs, salts, s2, ok) decoding.hpp:369-391
 //
-// Both run on the GPU through the C ABI of falcon_amd.h (libfalcon_amd.so); there is no CPU path
+// Everything lives in namespace falcon_gpu. Unless FALCON_AMD_NO_REFERENCE_NAMESPACE is defined, the same names
+// are also put into namespace falcon (the reference's own: a drop-in for code that includes this header INSTEAD of
+// the reference's falcon.hpp). A translation unit that includes BOTH libraries includes falcon_gpu.hpp, which
+// defines that macro, and calls falcon_gpu::verify<N> beside falcon::verify<N>.
+//
+// All of it runs on the GPU through the C ABI of falcon_amd.h (libfalcon_amd.so); there is no CPU path
 // in this header. Conventions are the reference's: the caller owns every
 // buffer, record lengths are implied by N (utils.hpp:9-17,39-49), the only per-item result is the
 // bool / accept byte. Errors of the device layer (no GPU, out of memory) are not representable in
@@ -35,7 +41,7 @@
 
 #include "falcon_amd.h"
 
-namespace falcon {
+namespace falcon_gpu {
 
 struct device_error : std::runtime_error {
   int code;
@@ -85,6 +91,13 @@ private:
   };
   slot slots_[16];
 };
+
+// size_t message length -> the C ABI's uint32_t; lengths the library cannot take throw instead of being truncated
+inline uint32_t msg_len(size_t mlen)
+{
+  if (mlen > FA_MAX_MSG_LEN) throw device_error("message length", FA_E_ARG);
+  return static_cast<uint32_t>(mlen);
+}
 
 inline fa_ctx* context(int device)
 {
@@ -159,7 +172,7 @@ inline void verify_many(size_t count, const uint8_t* pkeys, const uint8_t* msgs,
                         const uint8_t* sigs, uint8_t* accept, int device = 0, norm_policy policy = norm_policy::exact,
                         const fa_debug* debug = nullptr)
 {
-  const int rc = fa_verify_many(detail::context(device), detail::logn<N>(), count, pkeys, msgs, msg_off, (uint32_t)mlen,
+  const int rc = fa_verify_many(detail::context(device), detail::logn<N>(), count, pkeys, msgs, msg_off, detail::msg_len(mlen),
                                 sigs, (int)policy, accept, debug);
   if (rc) throw device_error("fa_verify_many", rc);
 }
@@ -172,48 +185,73 @@ inline void verify_many_device(size_t count, const uint8_t* d_pkeys, const uint8
                                void* stream = nullptr, norm_policy policy = norm_policy::exact)
 {
   const int rc = fa_verify_many_dev(detail::context(device), detail::logn<N>(), count, d_pkeys, d_msgs, d_msg_off,
-                                    (uint32_t)mlen, d_sigs, (int)policy, d_accept, nullptr, stream);
+                                    detail::msg_len(mlen), d_sigs, (int)policy, d_accept, nullptr, stream);
   if (rc) throw device_error("fa_verify_many_dev", rc);
 }
 
-// Multi-GPU form: the batch is cut into `ndev` contiguous ranges of
-// ceil(count/ndev) items, range g goes to device first_device+g on its own host thread and context,
-// and every range writes its slice of `accept` -- items are independent, so there is no collective
-// and nothing to merge beyond that concatenation. Messages must be fixed-stride or offset-indexed
-// as above (offsets are global, so every shard reads the same msgs/msg_off arrays).
+// Multi-GPU form: the batch is cut into devices.size() contiguous ranges of
+// ceil(count / devices.size()) items, range g goes to GPU devices[g] on its own host thread, and every range
+// writes its slice of `accept` -- items are independent, so there is no collective and nothing to merge beyond
+// that concatenation. Messages must be fixed-stride or offset-indexed as above (offsets are global, so every
+// shard reads the same msgs/msg_off arrays). A device may be named more than once (its ranges then run one after
+// the other on that GPU's shared context). `wire` is applied to each shared context for the call. If a range
+// fails, its slice of `accept` is zeroed and the first error is rethrown after all ranges have finished.
+template<size_t N>
+inline void verify_many_sharded(size_t count, const uint8_t* pkeys, const uint8_t* msgs, size_t mlen,
+                                const uint64_t* msg_off, const uint8_t* sigs, uint8_t* accept, const std::vector<int>& devices,
+                                norm_policy policy = norm_policy::exact, wire_format wire = wire_format::reference)
+{
+  const size_t ndev = devices.size();
+  if (ndev < 1) throw device_error("verify_many_sharded", FA_E_ARG);
+  const size_t per = (count + ndev - 1) / ndev;
+  std::vector<std::exception_ptr> errors(ndev);
+  auto run_range = [&](size_t g) noexcept {
+    const size_t lo = per * g < count ? per * g : count, hi = lo + per < count ? lo + per : count;
+    if (lo >= hi) return;
+    try {
+      detail::shared_context& sc = detail::shared_context_for(devices[g]);
+      std::lock_guard<std::mutex> hold(sc.lock);  // a context serves one host thread at a time
+      if (!sc.ctx) {
+        const int rc = fa_ctx_create(devices[g], &sc.ctx);
+        if (rc) throw device_error("fa_ctx_create", rc);
+      }
+      int rc = fa_set_option(sc.ctx, FA_OPT_WIRE_FORMAT, (int)wire);
+      if (rc) throw device_error("fa_set_option", rc);
+      // with msg_off the shard passes the whole message array and its own window of offsets
+      rc = fa_verify_many(sc.ctx, detail::logn<N>(), hi - lo, pkeys + lo * pkey_len<N>(), msg_off ? msgs : msgs + lo * mlen,
+                          msg_off ? msg_off + lo : nullptr, detail::msg_len(mlen), sigs + lo * sig_len<N>(), (int)policy, accept + lo,
+                          nullptr);
+      if (rc) throw device_error("fa_verify_many", rc);
+    } catch (...) {
+      for (size_t i = lo; i < hi; i++) accept[i] = 0;
+      errors[g] = std::current_exception();
+    }
+  };
+  std::vector<std::thread> workers;
+  size_t started = 1;  // the calling thread takes range 0
+  try {
+    workers.reserve(ndev);
+    for (; started < ndev; started++) workers.emplace_back(run_range, started);
+  } catch (...) {  // threads that could not be started (thread limit, bad_alloc): their ranges run inline below
+  }
+  run_range(0);
+  for (auto& w : workers) w.join();
+  for (size_t g = started; g < ndev; g++) run_range(g);
+  for (auto& e : errors)
+    if (e) std::rethrow_exception(e);
+}
+
+// The same over GPUs first_device .. first_device + ndev - 1.
 template<size_t N>
 inline void verify_many_sharded(size_t count, const uint8_t* pkeys, const uint8_t* msgs, size_t mlen,
                                 const uint64_t* msg_off, const uint8_t* sigs, uint8_t* accept, int ndev,
-                                int first_device = 0, norm_policy policy = norm_policy::exact)
+                                int first_device = 0, norm_policy policy = norm_policy::exact,
+                                wire_format wire = wire_format::reference)
 {
   if (ndev < 1) throw device_error("verify_many_sharded", FA_E_ARG);
-  const size_t per = (count + (size_t)ndev - 1) / (size_t)ndev;
-  std::vector<std::thread> workers;
-  std::vector<std::exception_ptr> errors((size_t)ndev);
-  for (int g = 0; g < ndev; g++) {
-    const size_t lo = per * (size_t)g, hi = lo + per < count ? lo + per : count;
-    if (lo >= hi) break;
-    workers.emplace_back([=, &errors] {
-      try {
-        detail::shared_context& sc = detail::shared_context_for(first_device + g);
-        std::lock_guard<std::mutex> hold(sc.lock);  // a context serves one host thread at a time
-        if (!sc.ctx) {
-          const int rc = fa_ctx_create(first_device + g, &sc.ctx);
-          if (rc) throw device_error("fa_ctx_create", rc);
-        }
-        // with msg_off the shard passes the whole message array and its own window of offsets
-        const int rc = fa_verify_many(sc.ctx, detail::logn<N>(), hi - lo, pkeys + lo * pkey_len<N>(),
-                                      msg_off ? msgs : msgs + lo * mlen, msg_off ? msg_off + lo : nullptr, (uint32_t)mlen,
-                                      sigs + lo * sig_len<N>(), (int)policy, accept + lo, nullptr);
-        if (rc) throw device_error("fa_verify_many", rc);
-      } catch (...) {
-        errors[(size_t)g] = std::current_exception();
-      }
-    });
-  }
-  for (auto& w : workers) w.join();
-  for (auto& e : errors)
-    if (e) std::rethrow_exception(e);
+  std::vector<int> devices((size_t)ndev);
+  for (int g = 0; g < ndev; g++) devices[(size_t)g] = first_device + g;
+  verify_many_sharded<N>(count, pkeys, msgs, mlen, msg_off, sigs, accept, devices, policy, wire);
 }
 
 // ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
@@ -255,7 +293,7 @@ inline void verify_many(size_t count, const prepared_keys<N>& keys, const uint32
                         norm_policy policy = norm_policy::exact)
 {
   const int rc = fa_verify_many_prepared(detail::context(device), detail::logn<N>(), count, keys.data(), keys.size(), key_idx,
-                                         msgs, msg_off, (uint32_t)mlen, sigs, (int)policy, accept, nullptr);
+                                         msgs, msg_off, detail::msg_len(mlen), sigs, (int)policy, accept, nullptr);
   if (rc) throw device_error("fa_verify_many_prepared", rc);
 }
 
@@ -264,7 +302,7 @@ template<size_t N>
 inline void hash_to_point_many(size_t count, const uint8_t* salts, const uint8_t* msgs, size_t mlen, const uint64_t* msg_off,
                                uint16_t* c, int device = 0)
 {
-  const int rc = fa_hash_to_point_many(detail::context(device), detail::logn<N>(), count, salts, msgs, msg_off, (uint32_t)mlen, c);
+  const int rc = fa_hash_to_point_many(detail::context(device), detail::logn<N>(), count, salts, msgs, msg_off, detail::msg_len(mlen), c);
   if (rc) throw device_error("fa_hash_to_point_many", rc);
 }
 
@@ -319,4 +357,26 @@ static inline bool verify(const uint8_t* __restrict pkey, const uint8_t* __restr
   return ok != 0;
 }
 
-}  // namespace falcon
+// verification::verify<N, beta2>(h, msg, mlen, sig) (verification.hpp:20-26; caller benchmarks/bench_signing.cpp:105):
+// one call with the public key kept decoded -- h is N coefficients in natural order, as decode_pkey leaves them
+// (the reference's ff_t is a uint16_t wrapper; any value is taken mod q as its arithmetic does). beta2 is implied
+// by N (falcon.hpp:245-246). A caller with many signatures per key prepares the key once (prepared_keys) instead.
+template<size_t N>
+static inline bool verify(const uint16_t* __restrict h, const uint8_t* __restrict msg, const size_t mlen,
+                          const uint8_t* __restrict sig, int device = 0)
+  requires((N == 512) || (N == 1024))
+{
+  const prepared_keys<N> key = prepared_keys<N>::from_decoded(1, h, device);
+  uint8_t ok = 0;
+  verify_many<N>(1, key, nullptr, msg, mlen, nullptr, sig, &ok, device);
+  return ok != 0;
+}
+
+}  // namespace falcon_gpu
+
+#ifndef FALCON_AMD_NO_REFERENCE_NAMESPACE
+// Drop-in spelling: the reference's own namespace, for code that includes this header instead of falcon.hpp.
+namespace falcon {
+using namespace falcon_gpu;
+}
+#endif

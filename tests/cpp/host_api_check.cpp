@@ -8,7 +8,8 @@
 // verify_many_sharded<N>. With <outdir>: the operators of the path through their C++ names -- decode_pkeys<N>,
 // decode_sigs<N>, hash_to_point_many<N> (on the decoded salts), ntt_many<N> / intt_many<N>, prepared_keys<N>::from_decoded
 // -- whose raw outputs go to <outdir>/{h,hok,salt,s2,sok,c,ntt,intt}.bin for the caller to compare; a fifth line holds
-// the accept flags of verify_many<N> over the keys prepared from the decoded polynomials.
+// the accept flags of verify_many<N> over the keys prepared from the decoded polynomials, a sixth those of the single-call
+// decoded-key verify<N>(h, msg, mlen, sig) on the first min(count, 8) items.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,8 @@ static void dump(const std::string& dir, const char* name, const std::vector<T>&
   f.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(T)));
 }
 
+static void stage(const char* what) { std::fprintf(stderr, "[host_api_check] %s\n", what); }
+
 template<size_t N>
 static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<uint8_t>& msg, std::vector<uint8_t>& sig, int ndev,
                const char* outdir)
@@ -45,16 +48,19 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     std::fprintf(stderr, "file sizes do not match count\n");
     return 2;
   }
+  stage("verify_many");
   std::vector<uint8_t> acc(count, 7);
   falcon::verify_many<N>(count, pk.data(), msg.data(), mlen, nullptr, sig.data(), acc.data());
   for (uint8_t a : acc) std::putchar('0' + a);
   std::putchar('\n');
+  stage("verify, one call per item");
   for (size_t i = 0; i < count && i < 8; i++) {
     const bool ok = falcon::verify<N>(pk.data() + i * falcon::pkey_len<N>(), msg.data() + i * mlen, mlen,
                                       sig.data() + i * falcon::sig_len<N>());
     std::putchar(ok ? '1' : '0');
   }
   std::putchar('\n');
+  stage("prepared keys");
   {  // decoded-key form: keys prepared once, item i against key i
     auto keys = falcon::prepared_keys<N>::from_encoded(count, pk.data());
     std::vector<uint8_t> acc3(count, 7);
@@ -62,6 +68,7 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     for (uint8_t a : acc3) std::putchar('0' + a);
     std::putchar('\n');
   }
+  stage("verify_many_sharded");
   std::vector<uint8_t> acc2(count, 7);
   falcon::pinned_buffer<uint8_t> ppk(pk.size());  // keys from pinned memory, the rest pageable
   std::copy(pk.begin(), pk.end(), ppk.data());
@@ -76,7 +83,34 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
   }
   for (uint8_t a : acc2) std::putchar('0' + a);
   std::putchar('\n');
+  stage("verify_many_sharded, several ranges on one GPU");
+  {  // two ranges mapped to GPU 0 twice (and three, with an empty-ish tail): both workers go through the one shared
+     // context of the device, one after the other under its mutex -- the multi-GPU path's host logic on a one-GPU box
+    for (const std::vector<int>& devs : { std::vector<int>{ 0, 0 }, std::vector<int>{ 0, 0, 0 } }) {
+      std::vector<uint8_t> two(count, 7);
+      falcon::verify_many_sharded<N>(count, ppk.data(), msg.data(), mlen, nullptr, sig.data(), two.data(), devs);
+      if (two != acc2) {
+        std::fprintf(stderr, "verify_many_sharded over %zu ranges on one GPU differs\n", devs.size());
+        return 5;
+      }
+    }
+    stage("verify_many_sharded, a device that does not exist");
+    bool threw = false;  // a device that does not exist: the error surfaces, the range's accept bytes are zeroed
+    std::vector<uint8_t> bad(count, 7);
+    try {
+      falcon::verify_many_sharded<N>(count, ppk.data(), msg.data(), mlen, nullptr, sig.data(), bad.data(), std::vector<int>{ 0, 63 });
+    } catch (const falcon::device_error&) {
+      threw = true;
+    }
+    const size_t per = (count + 1) / 2;
+    if (!threw || !std::equal(bad.begin(), bad.begin() + (std::ptrdiff_t)per, acc2.begin()) ||
+        std::any_of(bad.begin() + (std::ptrdiff_t)per, bad.end(), [](uint8_t a) { return a != 0; })) {
+      std::fprintf(stderr, "verify_many_sharded: failing range not reported / not zeroed\n");
+      return 6;
+    }
+  }
   if (outdir) {
+    stage("operators");
     std::vector<uint16_t> h(count * N, 0xAAAA), c(count * N), t(count * N), back(count * N);
     std::vector<int16_t> s2(count * N, 0x5555);
     std::vector<uint8_t> hok(count, 7), sok(count, 7), salt(count * 40, 0xEE);
@@ -94,7 +128,13 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     falcon::verify_many<N>(count, keys, nullptr, msg.data(), mlen, nullptr, sig.data(), acc5.data());
     for (uint8_t a : acc5) std::putchar('0' + a);
     std::putchar('\n');
+    stage("verify(h, ...), one call per item");
+    // the single-call form of the same: verification::verify<N, beta2>(h, msg, mlen, sig) (verification.hpp:20-26)
+    for (size_t i = 0; i < count && i < 8; i++)
+      std::putchar(falcon::verify<N>(h.data() + i * N, msg.data() + i * mlen, mlen, sig.data() + i * falcon::sig_len<N>()) ? '1' : '0');
+    std::putchar('\n');
   }
+  stage("done");
   return 0;
 }
 

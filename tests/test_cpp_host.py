@@ -22,7 +22,7 @@ def test_cpp_verify_and_verify_many(tmp_path, oracle, corpus, logn):
     out = subprocess.run([EXE, str(logn), str(count), "32", str(tmp_path / "pk.bin"), str(tmp_path / "msg.bin"),
                           str(tmp_path / "sig.bin"), "1", str(outdir)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    many, single, prepared, sharded, decoded_keys = out.stdout.split("\n")[:5]
+    many, single, prepared, sharded, decoded_keys, decoded_single = out.stdout.split("\n")[:6]
     want = "".join(str(int(f) & 1) for f in oracle.verify_many(logn, pk, msg, sig)[0])
     assert many == want
     assert single == want[:8]
@@ -53,3 +53,19 @@ def test_cpp_verify_and_verify_many(tmp_path, oracle, corpus, logn):
     for i, w in enumerate(zero_key_accepts):
         if w is not None:
             assert decoded_keys[i] == w, i
+    assert decoded_single == decoded_keys[:8]   # verify<N>(h, msg, mlen, sig), one call per item
+
+
+def test_both_headers_in_one_translation_unit(tmp_path):
+    """include/falcon_gpu.hpp beside a falcon::verify<N> with the reference's signature (and, where they were present at
+    build time, the reference's own decoding.hpp / ntt.hpp / utils.hpp): compiles, links, verifies the README triple."""
+    import json
+    exe = os.path.join(ROOT, "tests", "cpp", "both_headers_check")
+    assert os.path.exists(exe), "build tests/cpp first (__graft_entry__.build())"
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "readme_kat_falcon512.json")))
+    for name in ("pkey", "msg", "sig"):
+        (tmp_path / name).write_bytes(bytes.fromhex(k[name]))
+    out = subprocess.run([exe, str(tmp_path / "pkey"), str(tmp_path / "msg"), str(tmp_path / "sig")], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "verified 1 decode_pkey_agrees 1" in out.stdout

@@ -7,6 +7,9 @@ small cases item by item in test_gpu_parity.py; here it is sampled).
             messages rejects exactly that subset; the result does not depend on item order;
   config 4  Falcon-1024, 2^20 triples with the malformed mix: the accept byte equals what the class
             of each item dictates, and a sample agrees with the oracle under both norm policies.
+  config 5  one GPU's share of the mixed batch: 2^23 items, 50/50 Falcon-512 / Falcon-1024 (2^22 each, about 20 GB),
+            tiled on the device from 2^20-item corpora and verified in place by fa_verify_mixed_dev: the accept byte
+            of every item equals what its class dictates, a sample agrees with the oracle.
 """
 import numpy as np
 import pytest
@@ -107,3 +110,43 @@ def test_polymul_sixteen_million(ctx):
         want = orc.polymul(ai, bi, 9)
         assert ab[i].cpu().numpy().astype(np.uint16).tolist() == want.tolist()
         assert want.tolist() == orc.polymul(ai, bi, 9, schoolbook=True).tolist()
+
+
+def test_mixed_one_gpu_share_of_config5(ctx, corpus, oracle):
+    import torch
+    import mixed_batch
+    dev = torch.device("cuda", 0)
+    base, tile = 1 << 20, 4
+    p9 = corpus.generate(9, base, seed=0xC0FFEE, threads=16)
+    p10 = corpus.generate(10, base, seed=0xBADF00D, malformed_permille=250, threads=16)
+    npairs = base * tile
+    bits = mixed_batch.pair_order_bits(npairs, 55)
+    tags, pk_off, sig_off, msg_off, src = mixed_batch.layout(bits, 32)
+    bits_t = torch.from_numpy(bits).to(dev)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    t9, t10 = [up(a) for a in p9[:3]], [up(a) for a in p10[:3]]
+    d_pk = mixed_batch.pack_torch(bits_t, t9[0], t10[0], tile)
+    d_msg = mixed_batch.pack_torch(bits_t, t9[1], t10[1], tile)
+    d_sig = mixed_batch.pack_torch(bits_t, t9[2], t10[2], tile)
+    del t9, t10
+    d_tags, d_pko, d_sgo, d_mso = up(tags), up(pk_off.view(np.int64)), up(sig_off.view(np.int64)), up(msg_off.view(np.int64))
+    acc = torch.full((2 * npairs,), 7, dtype=torch.uint8, device=dev)
+    ctx.verify_mixed_dev(2 * npairs, d_tags.data_ptr(), d_pk.data_ptr(), d_pko.data_ptr(), d_msg.data_ptr(), d_mso.data_ptr(),
+                         d_sig.data_ptr(), d_sgo.data_ptr(), acc.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    del d_pk, d_sig, d_msg, acc
+    torch.cuda.empty_cache()
+    # class-dictated accept bytes: every Falcon-512 item is valid; a Falcon-1024 item is accepted iff its kind is a valid one
+    want10 = np.isin(p10[3], VALID_KINDS).astype(np.uint8)
+    triple = src % base                       # pair p uses triple p % base of each class
+    want = np.where(tags == 9, np.uint8(1), want10[triple])
+    np.testing.assert_array_equal(got, want)
+    assert (tags == 9).sum() == (tags == 10).sum() == npairs
+    # oracle sample: items of both classes from the last tile
+    idx = np.arange(2 * npairs - 8192, 2 * npairs)
+    i9, i10 = idx[tags[idx] == 9], idx[tags[idx] == 10]
+    o9 = oracle.verify_many(9, p9[0][triple[i9]], p9[1][triple[i9]], p9[2][triple[i9]], threads=16)[0] & 1
+    o10 = oracle.verify_many(10, p10[0][triple[i10]], p10[1][triple[i10]], p10[2][triple[i10]], threads=16)[0] & 1
+    np.testing.assert_array_equal(got[i9], o9)
+    np.testing.assert_array_equal(got[i10], o10)
