@@ -25,7 +25,8 @@ EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile",
            "fa_verify_many_prepared_dev", "fa_hash_to_point_many", "fa_hash_to_point_many_dev", "fa_compute_public_keys",
            "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister",
            "fa_ntt_many", "fa_ntt_many_dev", "fa_decode_pkeys", "fa_decode_pkeys_dev", "fa_decode_sigs", "fa_decode_sigs_dev",
-           "fa_finish", "fa_verify_many_dev_noalloc", "fa_verify_mixed_dev"]
+           "fa_finish", "fa_verify_many_dev_noalloc", "fa_verify_mixed_dev",
+           "fa_encode_pkeys", "fa_encode_pkeys_dev", "fa_compress_sigs", "fa_compress_sigs_dev"]
 
 
 class FaDebug(ctypes.Structure):
@@ -90,6 +91,10 @@ def load_library():
     lib.fa_decode_pkeys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     lib.fa_decode_sigs.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     lib.fa_decode_sigs_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+    lib.fa_encode_pkeys.argtypes = [vp, i32, sz, vp, vp]
+    lib.fa_encode_pkeys_dev.argtypes = [vp, i32, sz, vp, vp, vp]
+    lib.fa_compress_sigs.argtypes = [vp, i32, sz, vp, vp, vp]
+    lib.fa_compress_sigs_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     lib.fa_host_alloc.argtypes = [sz]
     lib.fa_host_alloc.restype = vp
     lib.fa_host_free.argtypes = [vp]
@@ -368,6 +373,31 @@ class Context:
         ok = np.zeros(count, np.uint8)
         _check(self.lib.fa_decode_sigs(self.handle, logn, count, _ptr(sig), _ptr(salt), _ptr(s2), _ptr(ok)), "fa_decode_sigs")
         return salt, s2, ok
+
+    def encode_pkeys(self, logn, h):
+        """encoding::encode_pkey (encoding.hpp:12-35) for every row of h (count, n) u16 -> (count, pklen) u8."""
+        h = np.ascontiguousarray(h, np.uint16)
+        count = h.shape[0]
+        if h.shape != (count, 1 << logn):
+            raise ValueError("h must be (count, n)")
+        pk = np.zeros((count, self.lib.fa_pkey_len(logn)), np.uint8)
+        _check(self.lib.fa_encode_pkeys(self.handle, logn, count, _ptr(h), _ptr(pk)), "fa_encode_pkeys")
+        return pk
+
+    def compress_sigs(self, logn, s2, sig=None):
+        """encoding::compress_sig (encoding.hpp:169-230) for every row of s2 (count, n) i16. sig (count, siglen) may be
+        passed in: only bytes 41.. of each row are written. Returns (sig, ok)."""
+        s2 = np.ascontiguousarray(s2, np.int16)
+        count = s2.shape[0]
+        if s2.shape != (count, 1 << logn):
+            raise ValueError("s2 must be (count, n)")
+        siglen = self.lib.fa_sig_len(logn)
+        sig = np.zeros((count, siglen), np.uint8) if sig is None else sig
+        if sig.dtype != np.uint8 or sig.shape != (count, siglen) or not sig.flags.c_contiguous:
+            raise ValueError("sig must be a contiguous (count, siglen) uint8 array")
+        ok = np.zeros(count, np.uint8)
+        _check(self.lib.fa_compress_sigs(self.handle, logn, count, _ptr(s2), _ptr(sig), _ptr(ok)), "fa_compress_sigs")
+        return sig, ok
 
     # ---- device-resident entry points (raw device pointers as ints) ----
     def verify_many_dev(self, logn, count, pk_ptr, msg_ptr, msg_off_ptr, mlen, sig_ptr, accept_ptr,

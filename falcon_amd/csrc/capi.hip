@@ -12,6 +12,7 @@
 
 #include "../../include/falcon_amd.h"
 #include "decode_kernel.hpp"
+#include "encode_kernel.hpp"
 #include "hash_kernel.hpp"
 #include "verify_kernel.hpp"
 #include "zq.hpp"
@@ -287,8 +288,8 @@ int h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t xs, Pi
   int rc = pin.reserve(bytes);
   if (rc) return rc;
   const size_t pieces = (bytes + PIECE - 1) / PIECE;
-  const unsigned nt = (unsigned)std::min<size_t>(threads, pieces);
-  std::vector<int> err(nt, 0);
+  const unsigned nt = (unsigned)std::min<size_t>(std::min(threads, 64u), pieces);
+  int err[64] = {};  // per worker; FA_OPT_HOST_THREADS is at most 64
   auto work = [&](unsigned t) {
     if (hipSetDevice(device) != hipSuccess) {
       err[t] = (int)hipErrorInvalidDevice;
@@ -303,13 +304,14 @@ int h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t xs, Pi
   std::vector<std::thread> pool;
   unsigned started = 1;  // the calling thread is worker 0
   try {
+    pool.reserve(nt);
     for (; started < nt; started++) pool.emplace_back(work, started);
   } catch (...) {  // no exception crosses the C ABI: the workers that did start still cover every piece below
   }
   work(0);
   for (auto& th : pool) th.join();
-  for (int e : err)
-    if (e) return e;
+  for (unsigned t = 0; t < started; t++)
+    if (err[t]) return err[t];
   // pieces of workers that could not be started
   for (unsigned t = started; t < nt; t++) {
     work(t);
@@ -1863,6 +1865,88 @@ int fa_decode_sigs(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(s2, ctx->h_c.p, s2_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(salt, ctx->h_msg.p, count * 40, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(ok, ctx->h_off.p, count, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- the encoders ----
+int fa_encode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* h, uint8_t* pk, void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!h || !pk || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if ((uintptr_t)h & 7u) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
+  if (logn == 9)
+    hipLaunchKernelGGL(encode_pkeys_kernel<9>, dim3(stride_grid(ctx, encode_pkeys_kernel<9>, want)), dim3(VERIFY_WG), 0, s, h, pk, n);
+  else
+    hipLaunchKernelGGL(encode_pkeys_kernel<10>, dim3(stride_grid(ctx, encode_pkeys_kernel<10>, want)), dim3(VERIFY_WG), 0, s, h, pk, n);
+  return (int)hipGetLastError();
+}
+
+int fa_encode_pkeys(fa_ctx* ctx, int logn, size_t count, const uint16_t* h, uint8_t* pk)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!h || !pk) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t in_bytes = (count << logn) * 2, out_bytes = count * fa_pkey_len(logn);
+  int rc;
+  if ((rc = ctx->h_a.reserve(in_bytes))) return rc;
+  if ((rc = ctx->h_pk.reserve(out_bytes + 8))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_a.p, h, in_bytes, hipMemcpyHostToDevice, s));
+  rc = fa_encode_pkeys_dev(ctx, logn, count, (const uint16_t*)ctx->h_a.p, (uint8_t*)ctx->h_pk.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(pk, ctx->h_pk.p, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int fa_compress_sigs_dev(fa_ctx* ctx, int logn, size_t count, const int16_t* s2, uint8_t* sig, uint8_t* ok, void* stream)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!s2 || !sig || !ok || count > 0xFFFFFFFFull) return FA_E_ARG;
+  if ((uintptr_t)s2 & 15u) return FA_E_ALIGN;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n = (uint32_t)count;
+  if (logn == 9)
+    hipLaunchKernelGGL(compress_sigs_kernel<9>, dim3((n + 63) / 64), dim3(64), 0, s, s2, n, sig, ok);
+  else
+    hipLaunchKernelGGL(compress_sigs_kernel<10>, dim3((n + 63) / 64), dim3(64), 0, s, s2, n, sig, ok);
+  return (int)hipGetLastError();
+}
+
+int fa_compress_sigs(fa_ctx* ctx, int logn, size_t count, const int16_t* s2, uint8_t* sig, uint8_t* ok)
+{
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (count == 0) return 0;
+  if (!s2 || !sig || !ok) return FA_E_ARG;
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  const size_t in_bytes = (count << logn) * 2, sig_bytes = count * fa_sig_len(logn);
+  int rc;
+  if ((rc = ctx->h_a.reserve(in_bytes))) return rc;
+  if ((rc = ctx->h_sig.reserve(sig_bytes + 16))) return rc;
+  if ((rc = ctx->h_off.reserve(count))) return rc;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->h_a.p, s2, in_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->h_sig.p, sig, sig_bytes, hipMemcpyHostToDevice, s));  // header and salt come along and go back untouched
+  rc = fa_compress_sigs_dev(ctx, logn, count, (const int16_t*)ctx->h_a.p, (uint8_t*)ctx->h_sig.p, (uint8_t*)ctx->h_off.p, s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(sig, ctx->h_sig.p, sig_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(ok, ctx->h_off.p, count, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;

@@ -239,6 +239,23 @@ int fa_decode_sigs(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint
 int fa_decode_sigs_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, uint8_t* salt, int16_t* s2, uint8_t* ok,
                        void* stream);
 
+/* ---- encoding::encode_pkey<N>(h, pkey), encoding.hpp:12-35, batched (the inverse of decode_pkey) ----
+ * h: count*N uint16, taken as they are (the reference packs h[i].v unmasked: a value >= 2^14 spills into the
+ * neighbouring field exactly as its expressions make it); pk: count*pklen bytes, header byte log2 N.
+ * _dev: device pointers (h 8-byte aligned), asynchronous on `stream`. */
+int fa_encode_pkeys(fa_ctx* ctx, int logn, size_t count, const uint16_t* h, uint8_t* pk);
+int fa_encode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* h, uint8_t* pk, void* stream);
+
+/* ---- encoding::compress_sig<N, sbytelen>(poly_s, sig), encoding.hpp:169-230, batched (the inverse of decompress_sig) ----
+ * s2: count*N int16 coefficients (the reference takes int32_t; the values a signer produces lie within [-2047, 2047]);
+ * sig: count*siglen bytes of which only bytes 41.. are written, as the reference does (:164-165): header and salt are
+ * the caller's; ok[i] = the reference's bool -- 0 when the code does not end before the last bit, and the body is then
+ * all zeros (:226-229). A code longer than the reference's own 14 N / 8-byte work buffer (possible only for
+ * coefficients far outside a signer's range) is undefined behaviour there; here it fails like any other code that is
+ * too long. _dev: device pointers (s2 16-byte aligned), asynchronous on `stream`. */
+int fa_compress_sigs(fa_ctx* ctx, int logn, size_t count, const int16_t* s2, uint8_t* sig, uint8_t* ok);
+int fa_compress_sigs_dev(fa_ctx* ctx, int logn, size_t count, const int16_t* s2, uint8_t* sig, uint8_t* ok, void* stream);
+
 /* Pinned host memory for the host-buffer entry points (no reference counterpart: the reference never
  * leaves the CPU). fa_host_alloc returns NULL on failure; fa_host_register pins an existing range
  * (page-granular, costly: worth it only for buffers that are reused; some hosts refuse it -- the MI355X boxes this

@@ -14,6 +14,8 @@
 //   falcon::ntt_many<N> / intt_many<N>(count, a, out)  ntt.hpp:120-150 / 161-200
 //   falcon::decode_pkeys<N>(count, pkeys, h, ok)       decoding.hpp:18-48
 //   falcon::decode_sigs<N>(count, sigs, salts, s2, ok) decoding.hpp:369-391
+//   falcon::encode_pkeys<N>(count, h, pkeys)           encoding.hpp:12-35
+//   falcon::compress_sigs<N>(count, s2, sigs, ok)      encoding.hpp:169-230
 //
 // Everything lives in namespace falcon_gpu. Unless FALCON_AMD_NO_REFERENCE_NAMESPACE is defined, the same names
 // are also put into namespace falcon (the reference's own: a drop-in for code that includes this header INSTEAD of
@@ -344,6 +346,23 @@ inline void decode_sigs(size_t count, const uint8_t* sigs, uint8_t* salts, int16
 {
   const int rc = fa_decode_sigs(detail::context(device), detail::logn<N>(), count, sigs, salts, s2, ok);
   if (rc) throw device_error("fa_decode_sigs", rc);
+}
+
+// encoding::encode_pkey<N>(h, pkey) (encoding.hpp:12-35) for `count` polynomials: the inverse of decode_pkeys.
+template<size_t N>
+inline void encode_pkeys(size_t count, const uint16_t* h, uint8_t* pkeys, int device = 0)
+{
+  const int rc = fa_encode_pkeys(detail::context(device), detail::logn<N>(), count, h, pkeys);
+  if (rc) throw device_error("fa_encode_pkeys", rc);
+}
+
+// encoding::compress_sig<N, sig_len<N>()>(poly_s, sig) (encoding.hpp:169-230) for `count` polynomials (int16 coefficients):
+// writes bytes 41.. of each signature only, ok[i] is the reference's bool (0: the code did not fit, body zeroed).
+template<size_t N>
+inline void compress_sigs(size_t count, const int16_t* s2, uint8_t* sigs, uint8_t* ok, int device = 0)
+{
+  const int rc = fa_compress_sigs(detail::context(device), detail::logn<N>(), count, s2, sigs, ok);
+  if (rc) throw device_error("fa_compress_sigs", rc);
 }
 
 // falcon.hpp:230-249. `sig` is non-const there too (never written).

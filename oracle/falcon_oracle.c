@@ -338,6 +338,61 @@ int fo_hash_to_point(unsigned logn, const uint8_t* salt, size_t slen, const uint
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Encoders, encoding.hpp:12-35 and 169-230 (wire-format adjacency) */
+/* ------------------------------------------------------------------------------------ */
+
+size_t fo_sig_len(unsigned logn);
+
+/* encode_pkey<N>, encoding.hpp:12-35: header byte log2 N, then each 4 coefficients -> 7 bytes, 14 bits each,
+ * little-endian. The reference takes the coefficients' 16-bit values as they are (h[i].v); for values >= 2^14 the
+ * high bits spill into the neighbouring field exactly as its expressions (casts to uint8_t, ORs) make them. */
+void fo_encode_pkey(unsigned logn, const uint16_t* h, uint8_t* pkey)
+{
+  const size_t n = (size_t)1 << logn;
+  pkey[0] = (uint8_t)logn;                                                         /* :22 */
+  for (size_t hoff = 0, pkoff = 1; hoff < n; hoff += 4, pkoff += 7) {              /* :23-34 */
+    pkey[pkoff + 0] = (uint8_t)h[hoff + 0];
+    pkey[pkoff + 1] = (uint8_t)(((uint8_t)(h[hoff + 1] & 0x03) << 6) | (uint8_t)(h[hoff + 0] >> 8));
+    pkey[pkoff + 2] = (uint8_t)(h[hoff + 1] >> 2);
+    pkey[pkoff + 3] = (uint8_t)(((uint8_t)(h[hoff + 2] & 0x0f) << 4) | (uint8_t)(h[hoff + 1] >> 10));
+    pkey[pkoff + 4] = (uint8_t)(h[hoff + 2] >> 4);
+    pkey[pkoff + 5] = (uint8_t)(((uint8_t)(h[hoff + 3] & 0x3f) << 2) | (uint8_t)(h[hoff + 2] >> 12));
+    pkey[pkoff + 6] = (uint8_t)(h[hoff + 3] >> 6);
+  }
+}
+
+/* compress_sig<N, sbytelen>, encoding.hpp:169-230: per coefficient a sign bit, the low 7 bits of |s|, |s| >> 7 zeros
+ * and a one, MSB first, into bytes 41.. of sig; fails (body zeroed, returns 0) when the code does not end before the
+ * last bit (bit_idx >= slen, :226-229). Bytes 0..40 are not touched (:164-165). The reference assembles the code in a
+ * stack buffer of 14 N / 8 bytes (:177-179) and writes past it when the code is longer than that (undefined behaviour,
+ * e.g. many |s| >= 2048): such inputs always have bit_idx >= slen, so here they simply fail, which is also what the
+ * reference returns whenever its overrun does no visible harm. INT32_MIN (std::abs overflows, :196) is outside the
+ * domain too; callers of the batched form pass int16 values. */
+int fo_compress_sig(unsigned logn, const int32_t* poly_s, uint8_t* sig)
+{
+  const size_t n = (size_t)1 << logn, sbytelen = fo_sig_len(logn);
+  const size_t slen = 8 * sbytelen - (8 + 320);                                    /* :176 */
+  const size_t body = sbytelen - 41;
+  uint8_t* out = sig + 41;
+  memset(out, 0, body);
+  size_t bit_idx = 0;
+  for (size_t i = 0; i < n; i++) {                                                 /* :184-224 */
+    const uint32_t mag = (uint32_t)(poly_s[i] < 0 ? -(int64_t)poly_s[i] : poly_s[i]);
+    const uint32_t head = ((poly_s[i] < 0 ? 1u : 0u) << 7) | (mag & 0x7fu);        /* sign, low 7 bits */
+    for (int b = 7; b >= 0; b--, bit_idx++)
+      if (((head >> b) & 1u) && (bit_idx >> 3) < body) out[bit_idx >> 3] |= (uint8_t)(0x80u >> (bit_idx & 7u));
+    bit_idx += mag >> 7;                                                           /* unary part: zeros ... */
+    if ((bit_idx >> 3) < body) out[bit_idx >> 3] |= (uint8_t)(0x80u >> (bit_idx & 7u));   /* ... and a one */
+    bit_idx++;
+  }
+  if (bit_idx >= slen) {                                                           /* :226-229 */
+    memset(out, 0, body);
+    return 0;
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* Decoders, decoding.hpp:18-48, 210-252, 267-361, 369-391; sizes utils.hpp:9-17,39-49    */
 /* ------------------------------------------------------------------------------------ */
 

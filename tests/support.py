@@ -70,6 +70,9 @@ class Oracle:
         lib.fo_decode_pkey.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_uint16)]
         lib.fo_decompress_sig.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_int32)]
         lib.fo_decode_sig.argtypes = [ctypes.c_uint, _u8p, _u8p, ctypes.POINTER(ctypes.c_int32)]
+        lib.fo_encode_pkey.argtypes = [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint16), _u8p]
+        lib.fo_encode_pkey.restype = None
+        lib.fo_compress_sig.argtypes = [ctypes.c_uint, ctypes.POINTER(ctypes.c_int32), _u8p]
         lib.fo_spec_decode_pkey.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_uint16)]
         lib.fo_spec_encode_pkey.argtypes = [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint16), _u8p]
         lib.fo_spec_decompress_sig.argtypes = [ctypes.c_uint, _u8p, ctypes.POINTER(ctypes.c_int32)]
@@ -120,6 +123,20 @@ class Oracle:
         s2 = np.zeros(1 << logn, np.int32) if s2 is None else s2
         ok = self.lib.fo_decode_sig(logn, _p(sig), _p(salt), _p(s2, ctypes.c_int32))
         return ok == 1, salt, s2  # 0: wrong header, -1: body does not decode
+
+    def encode_pkey(self, logn, h):
+        """encoding::encode_pkey (encoding.hpp:12-35)."""
+        h = np.ascontiguousarray(h, np.uint16)
+        pk = np.zeros(pk_len(logn), np.uint8)
+        self.lib.fo_encode_pkey(logn, _p(h, ctypes.c_uint16), _p(pk))
+        return pk
+
+    def compress_sig(self, logn, s2, sig=None):
+        """encoding::compress_sig (encoding.hpp:169-230): returns (ok, sig); bytes 0..40 of a passed-in sig are kept."""
+        s2 = np.ascontiguousarray(s2, np.int32)
+        sig = np.zeros(sig_len(logn), np.uint8) if sig is None else sig
+        ok = self.lib.fo_compress_sig(logn, _p(s2, ctypes.c_int32), _p(sig))
+        return bool(ok), sig
 
     # ---- specification wire format (no counterpart in the reference; oracle/falcon_oracle.c "Specification wire format") ----
     def spec_decode_pkey(self, logn, pk):

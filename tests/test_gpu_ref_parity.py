@@ -47,3 +47,24 @@ def test_operators_against_reference(ctx, corpus, logn):
     for i in range(48):
         np.testing.assert_array_equal(fwd[i], ref.ntt(a[i], logn))
         np.testing.assert_array_equal(inv[i], ref.ntt(a[i], logn, inverse=True))
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_encoders_against_reference(ctx, logn):
+    """The HIP encoders against the reference's own encode_pkey / compress_sig (encoding.hpp:12-35, 169-230)."""
+    n = 1 << logn
+    rng = np.random.default_rng(60 + logn)
+    count = 200
+    h = rng.integers(0, 12289, (count, n)).astype(np.uint16)
+    h[::4] = rng.integers(0, 65536, h[::4].shape).astype(np.uint16)
+    s2 = np.empty((count, n), np.int16)
+    for i in range(count):
+        s2[i] = np.rint(rng.normal(0, [30, 120, 165, 300][i % 4], n))
+    pk = ctx.encode_pkeys(logn, h)
+    sig, ok = ctx.compress_sigs(logn, s2)
+    for i in range(count):
+        np.testing.assert_array_equal(pk[i], ref.encode_pkey(logn, h[i]))
+        r_ok, r_sig = ref.compress_sig(logn, s2[i].astype(np.int32))
+        assert bool(ok[i]) == r_ok
+        np.testing.assert_array_equal(sig[i][41:], r_sig[41:])
+    assert 0 < ok.sum() < count
