@@ -500,7 +500,7 @@ int ws_end(fa_ctx* ctx, hipStream_t s)
 // Falcon-1024: 3.78 ms at 8 per CU, 3.48-3.52 ms at 24-48 (8-16 rounds).
 constexpr uint32_t GRID_ROUNDS = 12;
 template <typename K>
-uint32_t stride_grid(fa_ctx* ctx, K kernel, uint32_t want)
+uint32_t stride_grid(fa_ctx* ctx, K kernel, uint32_t want, int block = VERIFY_WG)
 {
   uint32_t per_cu = ctx->grid_per_cu;
   if (per_cu == 0) {  // resident workgroups per CU of this kernel, asked once
@@ -512,7 +512,7 @@ uint32_t stride_grid(fa_ctx* ctx, K kernel, uint32_t want)
     }
     if (per_cu == 0) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, VERIFY_WG, 0) != hipSuccess || nb < 1) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) {
         (void)hipGetLastError();
         nb = 8;
       }
@@ -681,10 +681,11 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
   A.item_base = item_base;
   A.half = ctx->wire == FA_WIRE_SPEC ? Q / 2u + 1u : Q / 2u;
   A.dbg = B.dbg;
-  const uint32_t want = (slots + VERIFY_WAVES - 1) / VERIFY_WAVES;
+  constexpr uint32_t VW = (uint32_t)verify_waves<LOGN>();
+  const uint32_t want = (slots + VW - 1) / VW;
   auto launch = [&](auto kernel) {
-    const uint32_t grid = stride_grid(ctx, kernel, want);
-    return timed(ctx, s, 2, [&] { hipLaunchKernelGGL(kernel, dim3(grid), dim3(VERIFY_WG), 0, s, A); });
+    const uint32_t grid = stride_grid(ctx, kernel, want, 64 * (int)VW);
+    return timed(ctx, s, 2, [&] { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * VW), 0, s, A); });
   };
   if (B.keys.pk.off || dcount) {  // the general instantiations: offset arrays, device-side count
     if (B.keys.prepared) return B.debug ? launch(verify_kernel<LOGN, true, true, true>) : launch(verify_kernel<LOGN, false, true, true>);
@@ -1041,10 +1042,10 @@ int fa_ctx_create(int device, fa_ctx** out)
     rc = FA_E_INTERNAL;
   }
   if (!rc) {  // resident workgroups per CU of the kernels the allocation-free entry point launches, asked now
-    (void)stride_grid(ctx, verify_kernel<9, false, false, false>, 1u);
-    (void)stride_grid(ctx, verify_kernel<10, false, false, false>, 1u);
-    (void)stride_grid(ctx, verify_kernel<9, false, false, true>, 1u);
-    (void)stride_grid(ctx, verify_kernel<10, false, false, true>, 1u);
+    (void)stride_grid(ctx, verify_kernel<9, false, false, false>, 1u, 64 * verify_waves<9>());
+    (void)stride_grid(ctx, verify_kernel<10, false, false, false>, 1u, 64 * verify_waves<10>());
+    (void)stride_grid(ctx, verify_kernel<9, false, false, true>, 1u, 64 * verify_waves<9>());
+    (void)stride_grid(ctx, verify_kernel<10, false, false, true>, 1u, 64 * verify_waves<10>());
   }
   if (rc) {
     fa_ctx_destroy(ctx);

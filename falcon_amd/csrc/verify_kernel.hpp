@@ -32,6 +32,11 @@ namespace fa {
 
 constexpr int VERIFY_WAVES = 4;  // waves per workgroup
 constexpr int VERIFY_WG = 64 * VERIFY_WAVES;
+// The verify kernel itself runs Falcon-1024 in workgroups of eight waves: its LDS is 17.4 KB of twiddle tables per
+// workgroup plus 6.4 KB per wave, so four-wave workgroups (43 KB) fit a CU three times = three waves per SIMD, eight-wave
+// ones (68.6 KB) twice = four; with the single register set of the item loop the kernel needs 128 VGPRs, which is what
+// four waves per SIMD allow.
+template <int LOGN> constexpr int verify_waves() { return LOGN == 10 ? 8 : 4; }
 
 template <int LOGN>
 struct Geo {
@@ -571,13 +576,14 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
 // pass). A template parameter rather than a run-time test because the two extra pointers cost the main instantiation its
 // fifth wave per SIMD (82 -> 101 VGPRs, scalar registers spilling to vector lanes: +11 % cycles, measured).
 template <int LOGN, bool DEBUG, bool PREPARED, bool GENERAL>
-__global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN> A)
+__global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const VerifyArgs<LOGN> A)
 {
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
+  constexpr int VW = verify_waves<LOGN>();
   __shared__ TwLds<LOGN> s_tw;
-  __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];  // transposes; the key row is staged in it before the first one
-  __shared__ uint16_t s_c[VERIFY_WAVES][N];
+  __shared__ uint32_t s_buf[VW][G::XBUF];  // transposes; the key row is staged in it before the first one
+  __shared__ uint16_t s_c[VW][N];
   static_assert(G::PKDW * 64 <= G::XBUF, "the key row fits the transpose buffer");
 
   fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);
@@ -587,26 +593,22 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
   uint32_t* pkb = buf;  // same wave, LDS operations of a wave complete in order: the fields are read before buf is rewritten
   uint16_t* cbuf = s_c[wave];
   const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
-  const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
+  const uint32_t nwaves = gridDim.x * VW;
 
-  uint32_t slot = blockIdx.x * VERIFY_WAVES + wave;
+  uint32_t slot = blockIdx.x * VW + wave;
   const uint32_t count = GENERAL && A.dcount ? min(A.count, *A.dcount) : A.count;
   if (slot >= count) return;
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED, GENERAL>(A, slot, lane, cur);
-  // The first item's loads are waited for here, once, before the loop. Without this the loop header inherits
-  // "loads into cur outstanding" from this path, hipcc's wait insertion cannot tell how many loads were issued
-  // since, and every iteration waited for ALL memory operations (s_waitcnt vmcnt(0)) right after issuing the next
-  // item's prefetch -- the prefetch hid nothing.
-  vmem_wait_all();
 
+  // One register set: an item's loaded words are consumed at the top of its iteration (sampling, s2 into x[], key fields
+  // into y[]), and the NEXT item's loads are then issued straight into the same registers, to arrive behind this item's
+  // transforms. (Round 1 kept two sets and copied nxt into cur at the end of every iteration: 21 v_mov per item and 21
+  // more live registers.) The loads are waited for once, at the top of the iteration that uses them.
   while (true) {
-    const uint32_t nslot = slot + nwaves;
-    const bool more = nslot < count;  // wave-uniform
-    ItemRegs<LOGN> nxt;
-    if (more) prefetch_item<LOGN, PREPARED, GENERAL>(A, nslot, lane, nxt);
-
-    const uint32_t item = cur.item;
+    vmem_wait_all();
+    const uint32_t item = __builtin_amdgcn_readfirstlane(cur.item);
+    const uint32_t sqn = __builtin_amdgcn_readfirstlane(cur.sqn);
     // header byte of the key row = byte `pal` of aligned dword 0 (lane 0 holds it); falcon.hpp:240-243
     uint32_t status = __builtin_amdgcn_readfirstlane(cur.st);
     if constexpr (PREPARED) {  // a key whose header was wrong is marked by 0xffff in its first coefficient
@@ -623,16 +625,20 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
       const uint32_t ndw = A.nblk * 34u;
       // `bounded`: the draws so far plus this round's 128 cannot exceed N, so no position needs checking
       auto sample = [&](uint32_t w, bool bounded = false) {
-        const uint32_t t0 = ((w & 0xffu) << 8) | ((w >> 8) & 0xffu);
-        const uint32_t t1 = ((w >> 8) & 0xff00u) | (w >> 24);
-        const bool a0 = t0 < 61445u, a1 = t1 < 61445u;
+        // both draws of the dword byte-swapped in place by one v_perm: t0 = low half, t1 = high half. t1 < 61445 is
+        // p < 61445 << 16 on the whole register, the stores take the halves as they lie (ds_write_b16 / _d16_hi), and the
+        // second draw's position is the first's plus one exactly in the lanes that accepted the first: two stores at a
+        // fixed distance under complementary masks instead of a per-lane address.
+        const uint32_t p = __builtin_amdgcn_perm(0u, w, 0x02030001u);
+        const bool a0 = (p & 0xffffu) < 61445u, a1 = p < (61445u << 16);
         const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
         // both draws of a lane come after all draws of the lanes below it: one prefix count over each mask, chained
         const uint32_t p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
                             __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, have))));
-        const uint32_t p1 = p0 + (a0 ? 1u : 0u);
-        if (a0 && (bounded || p0 < (uint32_t)N)) cbuf[p0] = (uint16_t)t0;
-        if (a1 && (bounded || p1 < (uint32_t)N)) cbuf[p1] = (uint16_t)t1;
+        uint16_t* dst = cbuf + p0;
+        if (a0 && (bounded || p0 < (uint32_t)N)) dst[0] = (uint16_t)p;
+        if (a1 && a0 && (bounded || p0 + 1u < (uint32_t)N)) dst[1] = (uint16_t)(p >> 16);
+        if (a1 && !a0 && (bounded || p0 < (uint32_t)N)) dst[0] = (uint16_t)(p >> 16);
         have += __popcll(m0) + __popcll(m1);
       };
 #pragma unroll
@@ -655,6 +661,33 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
       }
     }
 
+    // ---- what the transforms need, out of the loaded words: s2 (already lifted to [0,q), verification.hpp:36-39) and
+    //      the key ----
+    const bool run = status == ST_OK && !done;
+    int32_t x[R], y[R];
+    uint32_t hk[PREPARED ? R / 2 : 1], s2keep[DEBUG ? R : 1];
+    if (run) {
+#pragma unroll
+      for (int m = 0; m < R; m++) x[m] = (int32_t)cur.s2v[m];
+      if constexpr (DEBUG) {
+#pragma unroll
+        for (int m = 0; m < R; m++) s2keep[m] = cur.s2v[m];
+      }
+      if constexpr (PREPARED) {
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) hk[j] = cur.hk[j];
+      } else {
+        // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
+        //      lazily (equivalent to the reference's raw values, SURVEY.md section 8 a4). The row was loaded
+        //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
+        unpack_pkey<LOGN>(cur.pkw, cur.pal, pkb, lane, y);
+      }
+    }
+    // cur's registers are free: the next item's loads
+    const uint32_t nslot = slot + nwaves;
+    const bool more = nslot < count;  // wave-uniform
+    if (more) prefetch_item<LOGN, PREPARED, GENERAL>(A, nslot, lane, cur);
+
     if (status != ST_OK) {
       if (lane == 0) {
         A.accept[item] = 0;
@@ -672,24 +705,15 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
           if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = 0;
         }
       }
-    } else if (!done) {
-      // ---- s2 (already lifted to [0,q), verification.hpp:36-39) ----
-      int32_t x[R], y[R];
-#pragma unroll
-      for (int m = 0; m < R; m++) x[m] = (int32_t)cur.s2v[m];
-
+    } else if (run) {
       if constexpr (PREPARED) {
         ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) {  // NTT(h), canonical, already in this lane's phase-C positions
-          const uint32_t hv = (cur.hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
+          const uint32_t hv = (hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
           x[m] = mulmod_lazy(x[m], (int32_t)hv);  // polynomial.hpp:99-110; |x| <= 11q, hv < q
         }
       } else {
-        // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
-        //      lazily (equivalent to the reference's raw values, SURVEY.md section 8 a4). The row was loaded
-        //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
-        unpack_pkey<LOGN>(cur.pkw, cur.pal, pkb, lane, y);
         // One transform after the other: interleaving them (ntt_forward2) costs Falcon-1024 its third wave per SIMD
         // (31 more VGPRs, 17 KB more LDS) and, with the stages grouped by instruction kind, is 13 % slower.
         ntt_forward<LOGN>(y, T, buf, lane);
@@ -713,7 +737,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
           if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
           if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= A.half ? (int32_t)r - (int32_t)Q : (int32_t)r);
           if (A.dbg.s2) {
-            const uint32_t v = cur.s2v[m];
+            const uint32_t v = s2keep[m];
             A.dbg.s2[(size_t)item * N + i] = (int16_t)(v > Q / 2u ? (int32_t)v - (int32_t)Q : (int32_t)v);
           }
         }
@@ -721,7 +745,7 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
       // per-lane sums are < 2^30 but the wave total needs 36 bits: reduce the low 24 bits and the rest apart
       unsigned long long total = (unsigned long long)wave_sum_u32(acc & 0xffffffu) +
                                  ((unsigned long long)wave_sum_u32(acc >> 24) << 24);
-      total += cur.sqn;
+      total += sqn;
       const uint32_t wrapped = (uint32_t)total;
       const bool ok = A.wrap32 ? ((int32_t)wrapped <= (int32_t)G::BETA2) : (total <= (unsigned long long)G::BETA2);
       if (lane == 0) {
@@ -735,7 +759,6 @@ __global__ __launch_bounds__(VERIFY_WG) void verify_kernel(const VerifyArgs<LOGN
     }
     wave_lds_sync();  // cbuf / pkb / buf are reused by the next item
     if (!more) break;
-    cur = nxt;
     slot = nslot;
   }
 }
