@@ -16,14 +16,15 @@ ctx = capi.Context(0)
 orc = support.oracle()
 out = {}
 for logn, total in ((9, n9), (10, n10)):
-    bad = {"accept_exact": 0, "accept_wrap32": 0, "status": 0, "norm_exact": 0, "norm_wrap32": 0}
+    bad = {"accept_exact": 0, "accept_wrap32": 0, "status": 0, "norm_exact": 0, "norm_wrap32": 0, "accept_async_dev": 0,
+           "accept_noalloc": 0, "accept_prepared": 0}
     done = 0
     classes = {}
     t0 = time.time()
     step = 1 << 19
     for first in range(0, total, step):
         n = min(step, total - first)
-        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0221 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
+        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0222 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
         flags, odbg = orc.verify_many(logn, pk, msg, sig, debug=True, threads=16)
         acc, gdbg = ctx.verify_many(logn, pk, msg, sig, debug=True)
         accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)
@@ -32,6 +33,32 @@ for logn, total in ((9, n9), (10, n10)):
         bad["status"] += int((gdbg["status"] != odbg["status"]).sum())
         bad["norm_exact"] += int((gdbg["norm_exact"] != odbg["norm_exact"]).sum())
         bad["norm_wrap32"] += int((gdbg["norm_wrap32"] != odbg["norm_wrap32"]).sum())
+        # the same items device-resident: asynchronous call (device-side retry pass), the allocation-free entry point on
+        # 4096-item slices, and the prepared-key path
+        dev = torch.device("cuda", 0)
+        st = torch.cuda.current_stream().cuda_stream
+        t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (pk, msg, sig)]
+        d_acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        ctx.set_option(capi.OPT_ASYNC, 1)
+        ctx.verify_many_dev(logn, n, t[0].data_ptr(), t[1].data_ptr(), None, 32, t[2].data_ptr(), d_acc.data_ptr(), stream=st)
+        assert ctx.finish(st) == 0
+        ctx.set_option(capi.OPT_ASYNC, 0)
+        bad["accept_async_dev"] += int((d_acc.cpu().numpy() != (flags & 1)).sum())
+        d_acc.fill_(7)
+        pkl, sgl = pk.shape[1], sig.shape[1]
+        for c0 in range(0, min(n, 1 << 16), 4096):
+            m = min(4096, n - c0)
+            ctx.verify_many_dev_noalloc(logn, m, t[0].data_ptr() + c0 * pkl, t[1].data_ptr() + c0 * 32, None, 32,
+                                        t[2].data_ptr() + c0 * sgl, d_acc.data_ptr() + c0, stream=st)
+        m = min(n, 1 << 16)
+        bad["accept_noalloc"] += int((d_acc[:m].cpu().numpy() != (flags[:m] & 1)).sum())
+        d_prep = torch.empty((n, 1 << logn), dtype=torch.int16, device=dev)
+        ctx.prepare_keys_dev(logn, n, t[0].data_ptr(), None, d_prep.data_ptr(), stream=st)
+        d_acc.fill_(7)
+        ctx.verify_many_prepared_dev(logn, n, d_prep.data_ptr(), None, t[1].data_ptr(), None, 32, t[2].data_ptr(), d_acc.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        bad["accept_prepared"] += int((d_acc.cpu().numpy() != (flags & 1)).sum())
+        del t, d_acc, d_prep
         for k, c in zip(*np.unique(kinds, return_counts=True)):
             classes[int(k)] = classes.get(int(k), 0) + int(c)
         done += n
