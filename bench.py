@@ -273,6 +273,16 @@ def main():
                                           "rate_Tiops": REF_OPS_512[dom] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                                           "note": "SURVEY.md 8(d) cost model of the REFERENCE's operations (11 per butterfly, 4 transforms); "
                                                   "not a roofline fraction: the kernel does the same work in fewer instructions"}
+        ppath = os.path.join(ROOT, "profiles", "valu_peak_r01.json")   # tools/valu_peak.hip on an MI355X: single-instruction streams
+        if os.path.exists(ppath):
+            try:
+                rates = json.load(open(ppath))["rates_Tops"]
+                roof["peak_measured"] = {"source": "profiles/valu_peak_r01.json (tools/valu_peak.hip, SURVEY.md 8d: nominal and measured peak)",
+                                         "v_add_u32_Tiops": rates["v_add_u32"], "v_mad_u32_u24_Tiops": rates["v_mad_u32_u24"],
+                                         "v_bitop3_b32_Tiops": rates["v_bitop3_b32"], "v_alignbit_b32_Tiops": rates["v_alignbit_b32"],
+                                         "frac_of_measured_full_rate_peak": achieved / rates["v_add_u32"]}
+            except Exception as e:
+                log("no measured peak:", e)
         tpath = os.path.join(ROOT, PMC_SOURCE)
         if workload == "falcon512" and n_items == 1 << 20 and os.path.exists(tpath):
             try:   # counters of the same launch (2^20 Falcon-512 items), collected in separate rocprofv3 --pmc passes
@@ -312,6 +322,25 @@ def main():
             ts.append(time.perf_counter() - t0)
         ts.sort()
         return ts[len(ts) // 2], ts[0]
+
+    def leg_roofline(fn, items, ops_by_kernel, steps=3):
+        """Per-kernel HIP-event times of `steps` calls of fn -> the dominant kernel's roofline entry (as for the headline)."""
+        ctx.set_option(capi.OPT_PROFILE, 1)
+        fn()
+        ctx.get_profile()
+        for _ in range(steps):
+            fn()
+        pr = ctx.get_profile()
+        ctx.set_option(capi.OPT_PROFILE, 0)
+        ms = {"hash_kernel": pr["ms_hash"], "verify_kernel": pr["ms_verify"], "decode_kernel": pr["ms_decode"]}
+        nl = {"hash_kernel": pr["launches_hash"], "verify_kernel": pr["launches_verify"], "decode_kernel": pr["launches_decode"]}
+        k = max(ms, key=ms.get)
+        avg = ms[k] / max(nl[k], 1)
+        per_launch = items * steps / max(nl[k], 1)
+        ach = ops_by_kernel[k] * per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        return {"bound": "valu", "kernel": k, "achieved": ach, "peak": PEAK_VALU_TIOPS, "unit": "Tiop/s", "frac": ach / PEAK_VALU_TIOPS,
+                "avg_launch_ms": avg, "items_per_launch": per_launch, "algorithmic_ops_per_item": ops_by_kernel[k],
+                "kernels_ms_per_step": {a: b / steps for a, b in ms.items()}}
 
     if rank == 0 and world == 1 and not args.no_cpu and not mixed:
         # ---- CPU baseline: the oracle over a bounded sample of the same corpus ----
@@ -370,12 +399,17 @@ def main():
             ctx.verify_many_dev(10, ne, e_pk.data_ptr(), e_msg.data_ptr(), None, 32, e_sig.data_ptr(),
                                 e_acc.data_ptr(), stream=stream)
         med, best = timeit(step1024, reps=7, warm=3)
-        nchk = 1 << 14
+        nchk = 1 << 16
+        t0 = time.perf_counter()
         oflags, _ = support.oracle().verify_many(10, pk2[:nchk], msg2[:nchk], sig2[:nchk], threads=threads)
+        dt_cpu = time.perf_counter() - t0
         extras["falcon1024_malformed_mix"] = {
             "verifies_per_s": ne / med, "best": ne / best, "items": ne, "malformed_share": float((kinds2 != 0).mean()),
             "accepted_fraction": float(e_acc.float().mean().item()),
-            "accept_mismatches_vs_oracle_first_16384": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum())}
+            "accept_mismatches_vs_oracle_first_65536": int((e_acc[:nchk].cpu().numpy() != (oflags & 1)).sum()),
+            "roofline": leg_roofline(step1024, ne, ALG_OPS[10]),
+            "cpu_baseline": {"value": nchk / dt_cpu, "unit": "verifies/s", "cores": threads, "kind": "port",
+                             "sample": f"first {nchk} items of this corpus, {threads} pthreads"}}
         rate1024 = ne / med
         # mixed Falcon-512 + Falcon-1024 batch (BASELINE.json configs[4]): ONE GPU's share of the 64M-item batch, 2^23 items,
         # tiled on the device from the two 2^20-item corpora and verified in place by fa_verify_mixed_dev
@@ -393,7 +427,9 @@ def main():
                 "verifies_per_s": mx["count"] / med, "best": mx["count"] / best, "items": mx["count"], "share_1024": 0.5,
                 "harmonic_mean_of_single_class_rates": harm, "ratio_to_harmonic_mean": mx["count"] / med / harm,
                 "accept_mismatches_vs_single_class_paths_first_32768": int((got != np.where(tags == 9, f9[src], f10[src])).sum()),
-                "accepted_fraction": float(mx["accept"].float().mean().item())}
+                "accepted_fraction": float(mx["accept"].float().mean().item()),
+                "roofline": leg_roofline(lambda: run_mixed(mx), mx["count"],
+                                         {k: 0.5 * (ALG_OPS[9][k] + ALG_OPS[10][k]) for k in ALG_OPS[9]}, steps=2)}
             del mx
             torch.cuda.empty_cache()
         del e_pk, e_msg, e_sig, e_acc
