@@ -31,10 +31,12 @@ __global__ __launch_bounds__(64) void front_small_kernel(uint32_t nd, const Rows
                                                          uint8_t* __restrict__ st, uint32_t* __restrict__ slow_count,
                                                          uint32_t* __restrict__ slow_list, uint32_t spec,
                                                          const uint8_t* __restrict__ msg, const uint64_t* __restrict__ msg_off,
-                                                         uint32_t mlen, uint32_t nblk, uint64_t* __restrict__ hraw)
+                                                         uint32_t mlen, uint32_t nblk, uint64_t* __restrict__ hraw, uint32_t pair)
 {
   if (blockIdx.x < nd)  // workgroup-uniform
     decode_fast_body<LOGN>(blockIdx.x, sig, idx, count, dcount, s2, sqn, st, slow_count, slow_list, spec);
+  else if (pair)  // kernel argument: uniform. 32 items per hash wave, one sponge per lane pair (hash_kernel.hpp)
+    hash_pair_body(blockIdx.x - nd, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
   else
     hash_body<64>(blockIdx.x - nd, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
 }
@@ -408,6 +410,7 @@ struct fa_ctx {
   std::vector<hipEvent_t> ev_free;  // events ready for reuse (no hipEventCreate inside a timed loop)
   uint32_t retried = 0;
   uint32_t small_batch = 1u << 15;  // passes of at most this many items run decoder and hash waves in one kernel (front_small_kernel)
+  uint32_t pair_hash = 1u << 14;    // of those, passes of at most this many items hash with one sponge per lane pair (FA_OPT_PAIR_HASH_ITEMS)
   uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
   struct Resident {
     const void* kernel;
@@ -610,10 +613,11 @@ template <int LOGN>
 int front_small(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, const uint32_t* idx, const Batch& B, uint32_t nblk)
 {
   const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC), nd = (slots + 63) / 64;
+  const uint32_t pair = slots <= ctx->pair_hash ? 1u : 0u, nh = pair ? (slots + 31) / 32 : nd;
   HIP_TRY(hipMemsetAsync(ws.slow_count, 0, 256, s));
   int rc = timed(ctx, s, 1, [&] {  // booked as hash time: the hash waves are the longer half
-    hipLaunchKernelGGL(front_small_kernel<LOGN>, dim3(2 * nd), dim3(64), 0, s, nd, B.sig, idx, slots, (const uint32_t*)nullptr, ws.s2,
-                       ws.sqn, ws.st2, ws.slow_count, ws.slow_list, spec, B.msg, B.msg_off, B.mlen, nblk, ws.hraw);
+    hipLaunchKernelGGL(front_small_kernel<LOGN>, dim3(nd + nh), dim3(64), 0, s, nd, B.sig, idx, slots, (const uint32_t*)nullptr, ws.s2,
+                       ws.sqn, ws.st2, ws.slow_count, ws.slow_list, spec, B.msg, B.msg_off, B.mlen, nblk, ws.hraw, pair);
   });
   if (rc) return rc;
   return timed(ctx, s, 0, [&] {
@@ -1136,6 +1140,10 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
     case FA_OPT_SMALL_BATCH_ITEMS:
       if (value < 0 || value > (1 << 20)) return FA_E_ARG;
       ctx->small_batch = (uint32_t)value;
+      return 0;
+    case FA_OPT_PAIR_HASH_ITEMS:
+      if (value < 0 || value > (1 << 20)) return FA_E_ARG;
+      ctx->pair_hash = (uint32_t)value;
       return 0;
     case FA_OPT_GRID_PER_CU:
       if (value < 0 || value > 65536) return FA_E_ARG;

@@ -215,6 +215,170 @@ __device__ __forceinline__ void hash_body(uint32_t block, const Rows& sig,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small batches: one sponge per LANE PAIR. A pass of a few items is bound by the latency of one lane running
+// 9 (17) permutations of 24 x 180 instructions -- a lone wave issues an instruction every 5-6 cycles whatever its
+// lanes hold. Here the even lane of a pair keeps the low halves of the 25 Keccak lanes and the odd lane the high
+// halves: theta and chi work on halves independently, and a 64-bit rotation needs the partner's half of the same
+// word, one DPP quad_perm move away; with it both lanes compute their half of the rotated word by the SAME
+// v_alignbit (own, partner, 32 - r for r < 32; partner, own, 64 - r for r > 32). A round is 122 VALU instructions
+// instead of 180 (60 bitop3 on the halves, 29 exchanges, 29 alignbits); a wave serves 32 items. Measured, one
+// Falcon-512 item: 71 us instead of 86 (a lone wave issues the exchange-alignbit chains more slowly than the plain
+// stream, 5.9 against 4.9 cycles an instruction), Falcon-1024 126 instead of 151; it stays ahead up to 2^14 items a
+// pass and loses beyond (twice the hash waves). Used by front_small_kernel for passes of at most
+// FA_OPT_PAIR_HASH_ITEMS items.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t partner(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+}
+template <int R>
+__device__ __forceinline__ uint32_t rotl64_half(uint32_t own)  // this lane's half of rotl64(word, R)
+{
+  if constexpr (R == 0) {
+    return own;
+  } else if constexpr (R == 32) {
+    return partner(own);
+  } else if constexpr (R < 32) {
+    return __builtin_amdgcn_alignbit(own, partner(own), 32 - R);
+  } else {
+    return __builtin_amdgcn_alignbit(partner(own), own, 64 - R);
+  }
+}
+__device__ __forceinline__ uint32_t xor3h(uint32_t a, uint32_t b, uint32_t c)
+{
+  return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, 0x96);
+}
+
+__device__ __forceinline__ void keccak_round_pair(uint32_t (&a)[25], uint32_t rc)
+{
+  uint32_t c[5], r[5], b[25];
+#pragma unroll
+  for (int x = 0; x < 5; x++) c[x] = xor3h(xor3h(a[x], a[x + 5], a[x + 10]), a[x + 15], a[x + 20]);
+#pragma unroll
+  for (int x = 0; x < 5; x++) r[x] = rotl64_half<1>(c[x]);
+#pragma unroll
+  for (int i = 0; i < 25; i++) a[i] = xor3h(a[i], c[(i % 5 + 4) % 5], r[(i % 5 + 1) % 5]);
+  b[0] = a[0];
+  b[10] = rotl64_half<1>(a[1]);
+  b[20] = rotl64_half<62>(a[2]);
+  b[5] = rotl64_half<28>(a[3]);
+  b[15] = rotl64_half<27>(a[4]);
+  b[16] = rotl64_half<36>(a[5]);
+  b[1] = rotl64_half<44>(a[6]);
+  b[11] = rotl64_half<6>(a[7]);
+  b[21] = rotl64_half<55>(a[8]);
+  b[6] = rotl64_half<20>(a[9]);
+  b[7] = rotl64_half<3>(a[10]);
+  b[17] = rotl64_half<10>(a[11]);
+  b[2] = rotl64_half<43>(a[12]);
+  b[12] = rotl64_half<25>(a[13]);
+  b[22] = rotl64_half<39>(a[14]);
+  b[23] = rotl64_half<41>(a[15]);
+  b[8] = rotl64_half<45>(a[16]);
+  b[18] = rotl64_half<15>(a[17]);
+  b[3] = rotl64_half<21>(a[18]);
+  b[13] = rotl64_half<8>(a[19]);
+  b[14] = rotl64_half<18>(a[20]);
+  b[24] = rotl64_half<2>(a[21]);
+  b[9] = rotl64_half<61>(a[22]);
+  b[19] = rotl64_half<56>(a[23]);
+  b[4] = rotl64_half<14>(a[24]);
+#pragma unroll
+  for (int y = 0; y < 25; y += 5)
+#pragma unroll
+    for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+  a[0] ^= rc;
+}
+
+__device__ __forceinline__ void keccak_f1600_pair(uint32_t (&a)[25], uint32_t half)
+{
+  const uint32_t hi_lane = 0u - half;
+#pragma unroll 1
+  for (int round = 0; round < 24; round++) {
+    const uint32_t lo = KECCAK_RC_LO[round], hi = KECCAK_RC_HI[round];  // scalar loads
+    keccak_round_pair(a, lo ^ ((lo ^ hi) & hi_lane));
+  }
+}
+
+// hash_body for one wave of 32 items (workgroup = one wave). Same inputs, same hraw layout.
+__device__ __forceinline__ void hash_pair_body(uint32_t block, const Rows& sig, const uint8_t* __restrict__ msg,
+                                               const uint64_t* __restrict__ msg_off, uint32_t mlen,
+                                               const uint32_t* __restrict__ idx, uint32_t count, const uint32_t* __restrict__ dcount,
+                                               uint32_t nblk, uint64_t* __restrict__ hraw)
+{
+  __shared__ uint32_t stage[32 * 34];
+  const uint32_t lane = threadIdx.x & 63u, half = lane & 1u;
+  const uint32_t slot0 = block * 32u, slot = slot0 + (lane >> 1);
+  if (dcount) count = min(count, *dcount);
+  if (slot0 >= count) return;  // wave-uniform
+  const bool live = slot < count;
+  const uint32_t item = live ? (idx ? idx[slot] : slot) : 0u;
+
+  uint32_t a[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) a[i] = 0u;
+
+  // --- absorb salt || msg || pad (hashing.hpp:30-33): every lane takes its half of each 64-bit word. Both lanes of a
+  //     pair run the same number of blocks; idle pairs (beyond count) absorb nothing and are never stored. ---
+  int32_t nabs = 0, total = 0, ml = 0;
+  const uint32_t *sbase = nullptr, *mbase = nullptr;
+  uint32_t sal = 0, mal = 0;
+  if (live) {
+    const uint8_t* sp = sig.at(item) + 1;
+    sal = (uint32_t)((uintptr_t)sp & 3u);
+    sbase = (const uint32_t*)(sp - sal);
+    const uint8_t* mp;
+    if (msg_off) {
+      mp = msg + msg_off[item];
+      ml = (int32_t)(msg_off[item + 1] - msg_off[item]);
+    } else {
+      mp = msg + (size_t)item * mlen;
+      ml = (int32_t)mlen;
+    }
+    mal = (uint32_t)((uintptr_t)mp & 3u);
+    mbase = (const uint32_t*)(mp - mal);
+    total = 40 + ml;
+    nabs = total / 136 + 1;
+  }
+  // The permutation exchanges halves inside a pair only, and both lanes of a pair take the same trips (nabs is the
+  // pair's): the loop may diverge between pairs like hash_body's does between lanes.
+  for (int32_t blk = 0; blk < nabs; blk++) {
+#pragma unroll
+    for (int w = 0; w < 17; w++) {
+      const int32_t off = blk * 136 + w * 8 + 4 * (int32_t)half;  // stream offset of this lane's dword of the word
+      uint32_t v = off < 40 ? load_bytes4(sbase, sal, off, 40) : load_bytes4(mbase, mal, off - 40, ml);
+      if (total >= off && total < off + 4) v |= 0x1Fu << (8 * (total - off));  // SHAKE domain byte right after the data
+      if (w == 16 && half && blk == nabs - 1) v ^= 0x80000000u;                 // 0x80 on the last byte of the block
+      a[w] ^= v;
+    }
+    if (blk != nabs - 1) keccak_f1600_pair(a, half);
+  }
+
+  // --- squeeze nblk blocks (hashing.hpp:36-39) ---
+  const size_t row_words = (size_t)nblk * 17u;
+  const uint32_t rows = min(32u, count - slot0);
+  for (uint32_t b = 0; b < nblk; b++) {
+    keccak_f1600_pair(a, half);
+#pragma unroll
+    for (int w = 0; w < 17; w++) stage[(lane >> 1) * 34u + 2u * w + half] = a[w];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // 32 rows x 34 dwords, written as 17 coalesced wave stores
+    uint32_t* out = (uint32_t*)hraw;
+#pragma unroll
+    for (int t = 0; t < 17; t++) {
+      const uint32_t e = t * 64u + lane;
+      const uint32_t row = e / 34u, d = e - row * 34u;
+      if (row < rows) out[((size_t)(slot0 + row) * row_words + (size_t)b * 17u) * 2u + d] = stage[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 __global__ __launch_bounds__(HASH_WG, FA_HASH_WAVES) void hash_kernel(const Rows sig, const uint8_t* __restrict__ msg,
                                                        const uint64_t* __restrict__ msg_off, uint32_t mlen,
                                                        const uint32_t* __restrict__ idx, uint32_t count,

@@ -85,6 +85,14 @@ def test_message_lengths_and_ragged_offsets(ctx, oracle, corpus, logn):
     flags, odbg = oracle.verify_many(logn, pk, flat, sig, msg_off=off, debug=True, threads=8)
     acc, gdbg = ctx.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
     _compare_debug(logn, flags, odbg, acc, gdbg)
+    from falcon_amd import capi
+    c = capi.Context(0)  # the same through the other small-pass hash (the default context pairs lanes at this size)
+    try:
+        c.set_option(capi.OPT_PAIR_HASH_ITEMS, 0)
+        acc, gdbg = c.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
+        _compare_debug(logn, flags, odbg, acc, gdbg)
+    finally:
+        c.close()
 
 
 def test_empty_and_tiny_batches(ctx, oracle, corpus):
@@ -116,17 +124,18 @@ def test_chunked_passes_and_rehash(oracle, corpus, logn):
 
 @pytest.mark.parametrize("logn", [9, 10])
 def test_front_end_paths_and_grids(oracle, corpus, logn):
-    """The same batch through both front ends -- decoder and hash waves in one kernel (small passes) and one kernel
-    after the other (full passes) -- and with odd grids of the one-wave-per-item kernels (one workgroup, a
+    """The same batch through the front ends -- decoder and hash waves in one kernel (small passes; one sponge per lane
+    or per lane pair) and one kernel after the other (full passes) -- and with odd grids of the one-wave-per-item kernels (one workgroup, a
     prime per CU, more workgroups than items need): identical to the oracle each time."""
     from falcon_amd import capi
     pk, msg, sig, _ = corpus.generate(logn, 777, seed=31 + logn, malformed_permille=300)
     flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
     c = capi.Context(0)
     try:
-        for small, grid in ((0, 0), (1 << 20, 0), (0, 1), (1 << 20, 7), (0, 65536)):
+        for small, grid, pair in ((0, 0, 0), (1 << 20, 0, 0), (1 << 20, 0, 1 << 20), (0, 1, 0), (1 << 20, 7, 1 << 20), (0, 65536, 0)):
             c.set_option(capi.OPT_SMALL_BATCH_ITEMS, small)
             c.set_option(capi.OPT_GRID_PER_CU, grid)
+            c.set_option(capi.OPT_PAIR_HASH_ITEMS, pair)  # small passes: one sponge per lane or per lane pair
             acc, gdbg = c.verify_many(logn, pk, msg, sig, debug=True)
             _compare_debug(logn, flags, odbg, acc, gdbg)
             np.testing.assert_array_equal(c.verify_many(logn, pk, msg, sig), acc)

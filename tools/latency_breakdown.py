@@ -12,8 +12,8 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 for logn in (9, 10):
     pk, msg, sig, _ = support.corpus().generate(logn, 65536, seed=5)
-    for n, ov in [(n, ov) for n in (1, 64, 4096, 16384, 65536) for ov in (1 << 20, 0)]:
-        ctx.set_option(capi.OPT_SMALL_BATCH_ITEMS, ov)
+    for n, ov in [(n, ov) for n in (1, 64, 1024, 4096, 8192, 16384, 32768) for ov in (1 << 20, 0)]:
+        ctx.set_option(capi.OPT_PAIR_HASH_ITEMS, ov)
         d_pk, d_msg, d_sig = (torch.from_numpy(np.ascontiguousarray(a[:n])).to(dev) for a in (pk, msg, sig))
         d_acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         reps = 50
@@ -31,5 +31,5 @@ for logn in (9, 10):
         ctx.set_option(capi.OPT_PROFILE, 1); ctx.get_profile()
         for _ in range(reps): dev_call()
         p = ctx.get_profile(); ctx.set_option(capi.OPT_PROFILE, 0)
-        print(f"Falcon-{1 << logn} n={n} small_batch={ov}: host call {t_host*1e6:.0f} us, device call {t_dev*1e6:.0f} us, kernels "
+        print(f"Falcon-{1 << logn} n={n} pair_hash={ov}: host call {t_host*1e6:.0f} us, device call {t_dev*1e6:.0f} us, kernels "
               f"decode {p['ms_decode']*1e3/reps:.0f} + hash {p['ms_hash']*1e3/reps:.0f} + verify {p['ms_verify']*1e3/reps:.0f} us", flush=True)
