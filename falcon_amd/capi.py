@@ -14,6 +14,7 @@ NORM_EXACT64, NORM_WRAP32 = 0, 1
 ST_OK, ST_BAD_PK_HEADER, ST_BAD_SIG_HEADER, ST_BAD_ENCODING, ST_NORM_TOO_LARGE = range(5)
 OPT_CHUNK_ITEMS, OPT_HASH_BLOCKS_512, OPT_HASH_BLOCKS_1024, OPT_PROFILE, OPT_OVERLAP, OPT_HOST_CHUNK_ITEMS, OPT_HOST_THREADS, OPT_WIRE_FORMAT, OPT_GRID_PER_CU, OPT_SMALL_BATCH_ITEMS, OPT_ASYNC = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 OPT_PAIR_HASH_ITEMS = 12
+OPT_TINY_BATCH_ITEMS = 13
 E_ARG, E_LOGN, E_ALIGN, E_INTERNAL, E_UNRESOLVED, E_TOO_MANY = -1, -2, -3, -4, -5, -6
 NOALLOC_MAX_ITEMS = 4096
 MAX_MSG_LEN = 0x7fffff00

@@ -14,6 +14,7 @@
 #include "decode_kernel.hpp"
 #include "encode_kernel.hpp"
 #include "hash_kernel.hpp"
+#include "tiny_kernel.hpp"
 #include "verify_kernel.hpp"
 #include "zq.hpp"
 
@@ -39,6 +40,22 @@ __global__ __launch_bounds__(64) void front_small_kernel(uint32_t nd, const Rows
     hash_pair_body(blockIdx.x - nd, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
   else
     hash_body<64>(blockIdx.x - nd, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
+}
+
+// A handful of items (FA_OPT_TINY_BATCH_ITEMS): one decoder WAVE and one hash WAVE per item (tiny_kernel.hpp); the
+// first `count` workgroups decode, the rest hash. No fix-up queue: a signature the wave-parallel decoder cannot take
+// is decoded by the generic decoder inside the same wave.
+template <int LOGN>
+__global__ __launch_bounds__(64) void front_tiny_kernel(const Rows sig, const uint32_t* __restrict__ idx, uint32_t count,
+                                                        uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn, uint8_t* __restrict__ st,
+                                                        uint32_t spec, const uint8_t* __restrict__ msg,
+                                                        const uint64_t* __restrict__ msg_off, uint32_t mlen, uint32_t nblk,
+                                                        uint64_t* __restrict__ hraw)
+{
+  if (blockIdx.x < count)  // workgroup-uniform
+    decode_wave_body<LOGN>(blockIdx.x, sig, idx, s2, sqn, st, spec);
+  else
+    hash_wave_body(blockIdx.x - count, sig, msg, msg_off, mlen, idx, nblk, hraw);
 }
 
 // ---- mixed batches (fa_verify_mixed_dev): order-preserving split of the item indices by N ----
@@ -410,6 +427,7 @@ struct fa_ctx {
   std::vector<hipEvent_t> ev_free;  // events ready for reuse (no hipEventCreate inside a timed loop)
   uint32_t retried = 0;
   uint32_t small_batch = 1u << 15;  // passes of at most this many items run decoder and hash waves in one kernel (front_small_kernel)
+  uint32_t tiny_batch = 256;        // of those, passes of at most this many items run one wave per item (FA_OPT_TINY_BATCH_ITEMS)
   uint32_t pair_hash = 1u << 14;    // of those, passes of at most this many items hash with one sponge per lane pair (FA_OPT_PAIR_HASH_ITEMS)
   uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
   struct Resident {
@@ -613,6 +631,11 @@ template <int LOGN>
 int front_small(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, const uint32_t* idx, const Batch& B, uint32_t nblk)
 {
   const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC), nd = (slots + 63) / 64;
+  if (slots <= ctx->tiny_batch)  // one wave per item and stage, no fix-up pass
+    return timed(ctx, s, 1, [&] {
+      hipLaunchKernelGGL(front_tiny_kernel<LOGN>, dim3(2 * slots), dim3(64), 0, s, B.sig, idx, slots, ws.s2, ws.sqn, ws.st2, spec, B.msg,
+                         B.msg_off, B.mlen, nblk, ws.hraw);
+    });
   const uint32_t pair = slots <= ctx->pair_hash ? 1u : 0u, nh = pair ? (slots + 31) / 32 : nd;
   HIP_TRY(hipMemsetAsync(ws.slow_count, 0, 256, s));
   int rc = timed(ctx, s, 1, [&] {  // booked as hash time: the hash waves are the longer half
@@ -1140,6 +1163,10 @@ int fa_set_option(fa_ctx* ctx, int option, int64_t value)
     case FA_OPT_SMALL_BATCH_ITEMS:
       if (value < 0 || value > (1 << 20)) return FA_E_ARG;
       ctx->small_batch = (uint32_t)value;
+      return 0;
+    case FA_OPT_TINY_BATCH_ITEMS:
+      if (value < 0 || value > (1 << 20)) return FA_E_ARG;
+      ctx->tiny_batch = (uint32_t)value;
       return 0;
     case FA_OPT_PAIR_HASH_ITEMS:
       if (value < 0 || value > (1 << 20)) return FA_E_ARG;

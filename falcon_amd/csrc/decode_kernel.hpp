@@ -116,21 +116,12 @@ struct BitReader {
 // min(count, *dcount) when dcount is given (a device-side list length). For an item that fails, the s2 row
 // is left unspecified (nothing reads it).
 template <int LOGN>
-__global__ __launch_bounds__(DECODE_WG) void decode_kernel(const Rows sig, const uint32_t* __restrict__ list,
-                                                           const uint32_t* __restrict__ idx, uint32_t count,
-                                                           const uint32_t* __restrict__ dcount,
-                                                           uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
-                                                           uint8_t* __restrict__ st, uint32_t spec)
+__device__ __forceinline__ void decode_generic_item(const uint8_t* __restrict__ row, uint32_t slot, uint16_t* __restrict__ s2,
+                                                    uint32_t* __restrict__ sqn, uint8_t* __restrict__ st, uint32_t spec)
 {
   constexpr int N = 1 << LOGN;
   constexpr int SIGLEN = LOGN == 9 ? 666 : 1280;
   constexpr int32_t SLEN = 8 * SIGLEN;  // in bits, decoding.hpp:274
-  const uint32_t t = blockIdx.x * DECODE_WG + threadIdx.x;
-  if (dcount) count = min(count, *dcount);
-  if (t >= count) return;
-  const uint32_t slot = list ? list[t] : t;        // workspace slot (list: the fix-up pass behind decode_fast_kernel)
-  const uint32_t item = idx ? idx[slot] : slot;    // slot -> item of the caller's arrays
-  const uint8_t* row = sig.at(item);
 
   if (row[0] != (uint8_t)(0x30 | LOGN)) {  // decoding.hpp:376-382
     st[slot] = ST_BAD_SIG_HEADER;
@@ -220,6 +211,21 @@ __global__ __launch_bounds__(DECODE_WG) void decode_kernel(const Rows sig, const
   }
   st[slot] = failed ? ST_BAD_ENCODING : ST_OK;
   sqn[slot] = norm;
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(DECODE_WG) void decode_kernel(const Rows sig, const uint32_t* __restrict__ list,
+                                                           const uint32_t* __restrict__ idx, uint32_t count,
+                                                           const uint32_t* __restrict__ dcount,
+                                                           uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
+                                                           uint8_t* __restrict__ st, uint32_t spec)
+{
+  const uint32_t t = blockIdx.x * DECODE_WG + threadIdx.x;
+  if (dcount) count = min(count, *dcount);
+  if (t >= count) return;
+  const uint32_t slot = list ? list[t] : t;        // workspace slot (list: the fix-up pass behind decode_fast_kernel)
+  const uint32_t item = idx ? idx[slot] : slot;    // slot -> item of the caller's arrays
+  decode_generic_item<LOGN>(sig.at(item), slot, s2, sqn, st, spec);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -86,11 +86,13 @@ def test_message_lengths_and_ragged_offsets(ctx, oracle, corpus, logn):
     acc, gdbg = ctx.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
     _compare_debug(logn, flags, odbg, acc, gdbg)
     from falcon_amd import capi
-    c = capi.Context(0)  # the same through the other small-pass hash (the default context pairs lanes at this size)
+    c = capi.Context(0)  # the default context takes this size one wave per item; the same through the other small-pass fronts
     try:
-        c.set_option(capi.OPT_PAIR_HASH_ITEMS, 0)
-        acc, gdbg = c.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
-        _compare_debug(logn, flags, odbg, acc, gdbg)
+        for pair in (0, 1 << 20):
+            c.set_option(capi.OPT_TINY_BATCH_ITEMS, 0)
+            c.set_option(capi.OPT_PAIR_HASH_ITEMS, pair)
+            acc, gdbg = c.verify_many(logn, pk, flat, sig, msg_off=off, debug=True)
+            _compare_debug(logn, flags, odbg, acc, gdbg)
     finally:
         c.close()
 
@@ -132,15 +134,40 @@ def test_front_end_paths_and_grids(oracle, corpus, logn):
     flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
     c = capi.Context(0)
     try:
-        for small, grid, pair in ((0, 0, 0), (1 << 20, 0, 0), (1 << 20, 0, 1 << 20), (0, 1, 0), (1 << 20, 7, 1 << 20), (0, 65536, 0)):
+        for small, grid, pair, tiny in ((0, 0, 0, 0), (1 << 20, 0, 0, 0), (1 << 20, 0, 1 << 20, 0), (1 << 20, 0, 0, 1 << 20), (0, 1, 0, 0),
+                                        (1 << 20, 7, 1 << 20, 0), (0, 65536, 0, 0)):
             c.set_option(capi.OPT_SMALL_BATCH_ITEMS, small)
             c.set_option(capi.OPT_GRID_PER_CU, grid)
-            c.set_option(capi.OPT_PAIR_HASH_ITEMS, pair)  # small passes: one sponge per lane or per lane pair
+            c.set_option(capi.OPT_PAIR_HASH_ITEMS, pair)  # small passes: one sponge per lane or per lane pair ...
+            c.set_option(capi.OPT_TINY_BATCH_ITEMS, tiny)  # ... or one wave per item for decoder and sponge
             acc, gdbg = c.verify_many(logn, pk, msg, sig, debug=True)
             _compare_debug(logn, flags, odbg, acc, gdbg)
             np.testing.assert_array_equal(c.verify_many(logn, pk, msg, sig), acc)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_tiny_batches_every_count(ctx, oracle, corpus, logn):
+    """Counts 1..63 (and 64, 65, 256: the last size of the one-wave-per-item front) with every fourth item malformed:
+    decoded signature, hash-to-point, s1, norm and status identical to the oracle (falcon.hpp:230-249 one item at a
+    time is the case this path exists for)."""
+    pk, msg, sig, _ = corpus.generate(logn, 256, seed=900 + logn, malformed_permille=250)
+    flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
+    for n in list(range(1, 66)) + [256]:
+        acc, gdbg = ctx.verify_many(logn, pk[:n], msg[:n], sig[:n], debug=True)
+        _compare_debug(logn, flags[:n], odbg[:n], acc, gdbg)
+
+
+@pytest.mark.parametrize("kind", range(1, 13))
+@pytest.mark.parametrize("logn", [9, 10])
+def test_tiny_batches_malformed_classes(ctx, oracle, corpus, logn, kind):
+    """Every malformed class of the corpus (k >= 8 windows, -0, trailing bits, truncated codes ...) through the
+    wave-parallel decoder, which hands the shapes it does not take to the generic one inside the same wave."""
+    pk, msg, sig, _ = corpus.generate(logn, 64, seed=700 + kind, kind=kind)
+    flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
+    acc, gdbg = ctx.verify_many(logn, pk, msg, sig, debug=True)
+    _compare_debug(logn, flags, odbg, acc, gdbg)
 
 
 @pytest.mark.parametrize("per_class", [150, 9000])
