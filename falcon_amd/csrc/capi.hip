@@ -374,6 +374,12 @@ struct Workspace {
   uint8_t* st2 = nullptr;
   uint32_t cap_slots = 0;
   uint32_t* ctl = nullptr;         // CTL_WORDS counters (256 bytes), zeroed once per call: [CTL_RETRY], [CTL_UNRESOLVED]
+  // Number of items queued for a re-hash pass. Calls that end in a device-side retry pass count in ctl[CTL_RETRY]
+  // (the pass reads it as its size). Calls that synchronise count in a word of pinned host memory the GPU maps
+  // (host_counter = the host's address of it): the host zeroes it with a store and reads it after the stream
+  // synchronisation it makes anyway -- no memset and no device-to-host copy per call, which a one-item call notices.
+  uint32_t* retry_counter = nullptr;
+  volatile uint32_t* host_counter = nullptr;
   uint32_t* slow_count = nullptr;  // its own 256-byte block, zeroed before every fast-decoder launch
   uint32_t* retry_list = nullptr;  // items whose hash needs more blocks; as many entries as the call has items
   uint32_t* slow_list = nullptr;   // cap_slots entries
@@ -415,6 +421,8 @@ struct fa_ctx {
   DevBuf part_list, part_runs;  // mixed batches: the item indices split by N, per-run counts + totals
   uint32_t* d_unresolved = nullptr;  // running total of unresolved items of asynchronous calls (256-byte block)
   uint32_t* h_word = nullptr;        // pinned host words for small device-to-host reads
+  uint32_t* h_ctl = nullptr;         // pinned, GPU-mapped host word: the re-hash counter of synchronising calls (Workspace::host_counter)
+  uint32_t* d_hctl = nullptr;        // the GPU's address of it
   unsigned char* scratch = nullptr;  // this device's copy of the library's static scratch array (hipGetSymbolAddress)
   // staging for the host-buffer entry points; the verify pipeline double-buffers its per-item inputs
   struct HostStage {
@@ -592,6 +600,13 @@ int ws_from_ctx(fa_ctx* ctx, uint32_t slots, uint32_t nblk, size_t items, Worksp
                                                ctx->sqn.cap / 4, ctx->st2.cap, ctx->slow_list.cap / 4, (size_t)1 << 30 });
   ws.ctl = (uint32_t*)ctx->ctl.p;
   ws.slow_count = ws.ctl + CTL_WORDS;
+  if (ctx->async || ctx->quiet) {
+    ws.retry_counter = ws.ctl + CTL_RETRY;
+    ws.host_counter = nullptr;
+  } else {
+    ws.retry_counter = ctx->d_hctl;
+    ws.host_counter = ctx->h_ctl;
+  }
   ws.retry_list = (uint32_t*)ctx->retry_list.p;
   ws.slow_list = (uint32_t*)ctx->slow_list.p;
   ws.retry2_list = (uint32_t*)ctx->retry2_list.p;
@@ -761,16 +776,19 @@ template <int LOGN>
 int verify_enqueue(fa_ctx* ctx, const Workspace& ws, size_t count, const uint32_t* list, const Batch& B, hipStream_t s)
 {
   constexpr int T = LOGN - 9;
-  HIP_TRY(hipMemsetAsync(ws.ctl, 0, 256, s));
+  if (ws.host_counter)
+    *ws.host_counter = 0u;  // the previous call that used it has synchronised
+  else
+    HIP_TRY(hipMemsetAsync(ws.ctl, 0, 256, s));
   const uint32_t chunk = std::min<uint32_t>(ctx->chunk, ws.cap_slots);
   for (size_t c0 = 0; c0 < count; c0 += chunk) {
     const uint32_t slots = (uint32_t)std::min<size_t>(chunk, count - c0);
     int rc;
     if (list)
-      rc = run_pass<LOGN>(ctx, ws, s, slots, list + c0, nullptr, false, B, ctx->hash_blocks[T], 0u, ws.ctl + CTL_RETRY, ws.retry_list);
+      rc = run_pass<LOGN>(ctx, ws, s, slots, list + c0, nullptr, false, B, ctx->hash_blocks[T], 0u, ws.retry_counter, ws.retry_list);
     else  // the kernels see the chunk's window of the arrays; the retry list gets indices into the whole arrays
       rc = run_pass<LOGN>(ctx, ws, s, slots, nullptr, nullptr, false, window<LOGN>(B, c0), ctx->hash_blocks[T], (uint32_t)c0,
-                          ws.ctl + CTL_RETRY, ws.retry_list);
+                          ws.retry_counter, ws.retry_list);
     if (rc) return rc;
   }
   return 0;
@@ -787,20 +805,28 @@ int verify_finish(fa_ctx* ctx, Workspace& ws, uint32_t max_slots, size_t items, 
   uint32_t nblk = ctx->hash_blocks[T];
   for (;;) {
     uint32_t pending = 0;
-    HIP_TRY(hipMemcpyAsync(&pending, ws.ctl + CTL_RETRY, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (ws.host_counter) {
+      HIP_TRY(hipStreamSynchronize(s));
+      pending = *ws.host_counter;
+    } else {
+      HIP_TRY(hipMemcpyAsync(&pending, ws.ctl + CTL_RETRY, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
     if (pending == 0) break;
     ctx->retried += pending;
     nblk *= 2;
     DevBuf list;  // this round's list; the kernels refill ws.retry_list
     if ((rc = list.reserve((size_t)pending * 4))) return rc;
     rc = (int)hipMemcpyAsync(list.p, ws.retry_list, (size_t)pending * 4, hipMemcpyDeviceToDevice, s);
-    if (!rc) rc = (int)hipMemsetAsync(ws.ctl, 0, 256, s);
+    if (ws.host_counter)
+      *ws.host_counter = 0u;  // the stream is idle
+    else if (!rc)
+      rc = (int)hipMemsetAsync(ws.ctl, 0, 256, s);
     const uint32_t chunk = std::min<uint32_t>(ctx->chunk, std::max<uint32_t>(max_slots, 128u));
     if (!rc) rc = ws_from_ctx<LOGN>(ctx, std::min<uint32_t>(chunk, pending), nblk, items, ws);  // more blocks per item: a larger hraw
     for (uint32_t r0 = 0; !rc && r0 < pending; r0 += chunk) {
       const uint32_t slots = std::min<uint32_t>(chunk, pending - r0);
-      rc = run_pass<LOGN>(ctx, ws, s, slots, (const uint32_t*)list.p + r0, nullptr, true, B, nblk, 0u, ws.ctl + CTL_RETRY, ws.retry_list);
+      rc = run_pass<LOGN>(ctx, ws, s, slots, (const uint32_t*)list.p + r0, nullptr, true, B, nblk, 0u, ws.retry_counter, ws.retry_list);
     }
     if (!rc) rc = (int)hipStreamSynchronize(s);
     list.release();
@@ -819,7 +845,7 @@ int retry_tail(fa_ctx* ctx, const Workspace& ws, const Batch& B, hipStream_t s)
 {
   constexpr int T = LOGN - 9;
   const uint32_t cap = ws.tail_cap(), nblk = 2u * ctx->hash_blocks[T];
-  if (cap == 0 || (size_t)cap * nblk * 136 > ws.hraw_bytes) return FA_E_INTERNAL;
+  if (cap == 0 || (size_t)cap * nblk * 136 > ws.hraw_bytes || ws.retry_counter != ws.ctl + CTL_RETRY) return FA_E_INTERNAL;
   int rc = run_pass<LOGN>(ctx, ws, s, cap, ws.retry_list, ws.ctl + CTL_RETRY, true, B, nblk, 0u, ws.ctl + CTL_UNRESOLVED, ws.retry2_list);
   if (rc) return rc;
   hipLaunchKernelGGL(retry_account_kernel, dim3(1), dim3(1), 0, s, ws.ctl, cap, ctx->quiet ? (uint32_t*)nullptr : ctx->d_unresolved);
@@ -980,6 +1006,7 @@ Workspace ws_from_scratch(unsigned char* sp)
   Workspace ws;
   ws.ctl = (uint32_t*)(sp + SC_CTL);
   ws.slow_count = ws.ctl + CTL_WORDS;
+  ws.retry_counter = ws.ctl + CTL_RETRY;
   ws.s2 = (uint16_t*)(sp + SC_S2);
   ws.hraw = (uint64_t*)(sp + SC_HRAW);
   ws.hraw_bytes = NOALLOC_ITEMS * 17 * 136;
@@ -1050,6 +1077,9 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMalloc((void**)&ctx->d_unresolved, 256);
     if (!rc) rc = (int)hipMemset(ctx->d_unresolved, 0, 256);
     if (!rc) rc = (int)hipHostMalloc((void**)&ctx->h_word, 64, hipHostMallocDefault);
+    if (!rc) rc = (int)hipHostMalloc((void**)&ctx->h_ctl, 256, hipHostMallocMapped | hipHostMallocCoherent);
+    if (!rc) rc = (int)hipHostGetDevicePointer((void**)&ctx->d_hctl, ctx->h_ctl, 0);
+    if (!rc) *ctx->h_ctl = 0u;
     if (!rc) rc = scratch_address(device, &ctx->scratch);  // this device current (Guard above)
   }
   for (int t = 0; t < 2 && !rc; t++) try {
@@ -1106,6 +1136,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
   }
   if (ctx->d_unresolved) (void)hipFree(ctx->d_unresolved);
   if (ctx->h_word) (void)hipHostFree(ctx->h_word);
+  if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
   DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->ctl, &ctx->retry_list, &ctx->slow_list, &ctx->retry2_list,
                      &ctx->part_list, &ctx->part_runs, &ctx->h_pk, &ctx->h_sig, &ctx->h_msg, &ctx->h_off, &ctx->h_a, &ctx->h_b,
                      &ctx->h_c, &ctx->h_off2, &ctx->h_off3, &ctx->h_tag, &ctx->spec_pk };

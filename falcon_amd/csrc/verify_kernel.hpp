@@ -654,7 +654,8 @@ __global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const
       }
       if (have < (uint32_t)N) {  // vanishingly rare: this item is hashed again with more blocks (host loop or retry pass)
         if (lane == 0) {
-          A.retry_list[atomicAdd(A.retry_count, 1u)] = A.item_base + item;
+          // system scope: the counter of a synchronising call lives in host memory the GPU maps (capi.hip, Workspace)
+          A.retry_list[__hip_atomic_fetch_add(A.retry_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)] = A.item_base + item;
           A.accept[item] = 0;  // defined until then
         }
         done = true;
