@@ -429,6 +429,7 @@ struct fa_ctx {
     DevBuf pk, sig, msg, off, kidx, accept, dbg[6];
     PinBuf pin_pk, pin_sig, pin_msg;  // pinned staging for pageable caller memory
   } hs[2];
+  PinBuf zc;  // tiny host-buffer calls: inputs and accept bytes in pinned host memory the kernels read and write in place
   uint32_t host_threads = 6;  // host threads staging pageable memory (0: leave it to the runtime)
   DevBuf h_pk, h_sig, h_msg, h_off, h_a, h_b, h_c, h_off2, h_off3, h_tag;
   std::vector<EventPair> events;
@@ -1148,6 +1149,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
     st.pin_pk.release();
     st.pin_sig.release();
     st.pin_msg.release();
+    ctx->zc.release();
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -1495,6 +1497,45 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   hipStream_t cs = ctx->stream, xs = ctx->copy;
   int rc;
   if ((rc = ws_begin(ctx, cs))) return rc;
+
+  // A handful of items (the one-wave-per-item front, FA_OPT_TINY_BATCH_ITEMS): three staged copies, two events and
+  // the copy back cost more than the kernels take. The inputs are gathered in pinned host memory instead, which the
+  // kernels read in place over the host link (a few KB per item, read once), and the accept bytes are written there
+  // too: no copy engine, one synchronisation. One Falcon-512 item: 98 -> about 55 us per call.
+  constexpr size_t ZC_MAX_BYTES = 1u << 20;
+  if (!prepared && !dbg && count <= ctx->tiny_batch) {
+    auto up = [](size_t v) { return (v + 63u) & ~(size_t)63u; };
+    const size_t first = msg_off ? (size_t)msg_off[0] : 0;
+    const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;
+    const size_t o_pk = 0, o_sig = up(o_pk + count * pklen + 8), o_msg = up(o_sig + count * siglen + 8);
+    const size_t o_off = up(o_msg + msg_bytes + 16), o_acc = up(o_off + (msg_off ? (count + 1) * 8 : 0)), total = up(o_acc + count);
+    if (total <= ZC_MAX_BYTES) {
+      if ((rc = ctx->zc.reserve(ZC_MAX_BYTES))) return rc;
+      uint8_t* h = (uint8_t*)ctx->zc.p;
+      uint8_t* d = nullptr;
+      HIP_TRY(hipHostGetDevicePointer((void**)&d, h, 0));
+      memcpy(h + o_pk, pk, count * pklen);
+      memcpy(h + o_sig, sig, count * siglen);
+      const size_t m0 = o_msg + (first & 3u);  // message bytes land at their offset modulo 4: the kernels' base stays aligned
+      if (msg_bytes) memcpy(h + m0, msg + (msg_off ? first : 0), msg_bytes);
+      if (msg_off) memcpy(h + o_off, msg_off, (count + 1) * 8);
+      Batch B;
+      B.policy = norm_policy;
+      B.mlen = mlen;
+      B.keys.pk = Rows{ d + o_pk, nullptr, (uint32_t)pklen };
+      B.sig = Rows{ d + o_sig, nullptr, (uint32_t)siglen };
+      B.msg = d + m0 - first;
+      B.msg_off = msg_off ? (const uint64_t*)(d + o_off) : nullptr;
+      B.accept = d + o_acc;
+      if (ctx->wire == FA_WIRE_SPEC && (rc = keys_in_reference_form(ctx, logn, cs, B.keys.pk.base, count, &B.keys.pk.base))) return rc;
+      Workspace ws;
+      rc = logn == 9 ? ws_from_ctx<9>(ctx, (uint32_t)count, ctx->hash_blocks[0], count, ws) : ws_from_ctx<10>(ctx, (uint32_t)count, ctx->hash_blocks[1], count, ws);
+      if (!rc) rc = logn == 9 ? verify_enqueue<9>(ctx, ws, count, nullptr, B, cs) : verify_enqueue<10>(ctx, ws, count, nullptr, B, cs);
+      if (!rc) rc = logn == 9 ? verify_finish<9>(ctx, ws, (uint32_t)count, count, B, cs) : verify_finish<10>(ctx, ws, (uint32_t)count, count, B, cs);
+      if (!rc) memcpy(accept, h + o_acc, count);  // verify_finish has synchronised the stream
+      return rc;
+    }
+  }
 
   const uint16_t* d_prepared = nullptr;
   if (prepared) {  // the key table is shared by all sub-batches: staged once, ahead of the first kernel
