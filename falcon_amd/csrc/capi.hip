@@ -436,7 +436,7 @@ struct fa_ctx {
   std::vector<hipEvent_t> ev_free;  // events ready for reuse (no hipEventCreate inside a timed loop)
   uint32_t retried = 0;
   uint32_t small_batch = 1u << 15;  // passes of at most this many items run decoder and hash waves in one kernel (front_small_kernel)
-  uint32_t tiny_batch = 256;        // of those, passes of at most this many items run one wave per item (FA_OPT_TINY_BATCH_ITEMS)
+  uint32_t tiny_batch = 512;        // of those, passes of at most this many items run one wave per item (FA_OPT_TINY_BATCH_ITEMS)
   uint32_t pair_hash = 1u << 14;    // of those, passes of at most this many items hash with one sponge per lane pair (FA_OPT_PAIR_HASH_ITEMS)
   uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
   struct Resident {
@@ -1502,7 +1502,7 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   // the copy back cost more than the kernels take. The inputs are gathered in pinned host memory instead, which the
   // kernels read in place over the host link (a few KB per item, read once), and the accept bytes are written there
   // too: no copy engine, one synchronisation. One Falcon-512 item: 98 -> about 55 us per call.
-  constexpr size_t ZC_MAX_BYTES = 1u << 20;
+  constexpr size_t ZC_MAX_BYTES = 2u << 20;
   if (!prepared && !dbg && count <= ctx->tiny_batch) {
     auto up = [](size_t v) { return (v + 63u) & ~(size_t)63u; };
     const size_t first = msg_off ? (size_t)msg_off[0] : 0;

@@ -4,14 +4,18 @@
 // 64: 42 us to decode one Falcon-512 signature, 71-86 us to squeeze its nine SHAKE256 blocks -- a lone wave issues an
 // instruction every 5-6 cycles whatever its lanes hold. A caller with one signature (falcon::verify<N>,
 // falcon.hpp:230-249) waits for exactly that. Here a wave spreads ONE item over its lanes:
-//   * hash_wave_body: the 25 x 64-bit Keccak state lives in 50 lanes (one half-word per lane), a round is 22 vector
-//     instructions, nine of them ds_bpermute, instead of 180 (hashing.hpp:30-39, sha3 submodule);
+//   * hash_wave_body: the 25 x 64-bit Keccak state lives in 50 lanes (one half-word per lane), a round is 20 vector
+//     instructions, nine of them ds_bpermute, instead of 180 (hashing.hpp:30-39, sha3 submodule). Measured 148 ns a
+//     round, bound by the two LDS round trips in it (unrolling and trimming the instruction stream changed nothing):
+//     nine blocks in 31 us instead of 71-86;
 //   * decode_wave_body: the code boundaries of the compressed signature are found by pointer doubling over all bit
 //     positions (decoding.hpp:267-361): next(p) = p + 9 + k(p) for every p, then next^2, next^4, ... in LDS; the
 //     position of coefficient i is the composition of the tables named by the bits of i.
 // Both leave exactly what their lane-per-item counterparts leave in the workspace (s2 tiles, sqn, status, hraw rows),
 // so the verify kernel that follows is the same. front_tiny_kernel (capi.hip) runs one decoder wave and one hash wave
-// per item.
+// per item; the decoder wave (about 10 / 20 us) finishes well inside the hash wave's time. Device-resident call, one
+// item: 48 us (Falcon-512), 82 us (Falcon-1024) against 102 / 162 for the lane-per-item front; ahead of it up to about
+// 1,024 (512) items a pass, where the decoder's LDS tables (21 / 41 KB a wave) limit how many waves a CU holds.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
