@@ -508,6 +508,30 @@ def main():
                                   "roofline_hbm": {"bound": "hbm", "achieved": npoly / med * 3072 / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                    "frac": npoly / med * 3072 / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_item": 3072}}
         del a, b, c
+        # one signature per call (falcon::verify<N>, falcon.hpp:230-249, the reference's own per-call benchmark shape,
+        # README.md:150-167: 20-44 us on a CPU core): wall time of a device-resident call and of a host-buffer call
+        lat = {}
+        for ln, (lpk, lmsg, lsig) in ((9, (pk, msg, sig)), (10, (pk2, msg2, sig2))):
+            one = [torch.from_numpy(np.ascontiguousarray(x[:1])).to(dev) for x in (lpk, lmsg, lsig)]
+            one_acc = torch.zeros(1, dtype=torch.uint8, device=dev)
+
+            def dev_one():
+                ctx.verify_many_dev(ln, 1, one[0].data_ptr(), one[1].data_ptr(), None, 32, one[2].data_ptr(), one_acc.data_ptr(), stream=stream)
+            for _ in range(20):
+                dev_one()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                dev_one()  # synchronises its stream itself (no FA_OPT_ASYNC): nothing is left in flight
+            med_d = (time.perf_counter() - t0) / 200
+            t_h = []
+            for _ in range(220):
+                t0 = time.perf_counter()
+                ctx.verify_many(ln, lpk[:1], lmsg[:1], lsig[:1])
+                t_h.append(time.perf_counter() - t0)
+            t_h = sorted(t_h[20:])
+            lat[f"falcon{1 << ln}"] = {"device_resident_call_us": med_d * 1e6, "host_buffer_call_us": t_h[len(t_h) // 2] * 1e6,
+                                           "note": "mean of 200 device-resident calls, median of 200 host-buffer calls"}
+        extras["one_item_per_call_latency"] = lat
         result["extras"] = extras
 
     if rank == 0:
