@@ -17,14 +17,14 @@ orc = support.oracle()
 out = {}
 for logn, total in ((9, n9), (10, n10)):
     bad = {"accept_exact": 0, "accept_wrap32": 0, "status": 0, "norm_exact": 0, "norm_wrap32": 0, "accept_async_dev": 0,
-           "accept_noalloc": 0, "accept_prepared": 0}
+           "accept_noalloc": 0, "accept_prepared": 0, "accept_small_calls": 0, "status_small_calls": 0, "norm_small_calls": 0}
     done = 0
     classes = {}
     t0 = time.time()
     step = 1 << 19
     for first in range(0, total, step):
         n = min(step, total - first)
-        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0222 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
+        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0223 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
         flags, odbg = orc.verify_many(logn, pk, msg, sig, debug=True, threads=16)
         acc, gdbg = ctx.verify_many(logn, pk, msg, sig, debug=True)
         accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)
@@ -59,6 +59,19 @@ for logn, total in ((9, n9), (10, n10)):
         torch.cuda.synchronize()
         bad["accept_prepared"] += int((d_acc.cpu().numpy() != (flags & 1)).sum())
         del t, d_acc, d_prep
+        # the first 2^15 items again in calls of a few items to a few thousand: the one-wave-per-item front (<= 512), its
+        # copy-free host path, the lane-pair sponge (<= 2^14)
+        sizes, c0, k = (1, 2, 3, 5, 17, 64, 65, 100, 333, 512, 513, 1000, 4096), 0, 0
+        while c0 < min(n, 1 << 15):
+            m = min(sizes[k % len(sizes)], n - c0)
+            sl = slice(c0, c0 + m)
+            a1 = ctx.verify_many(logn, pk[sl], msg[sl], sig[sl])
+            a2, g2 = ctx.verify_many(logn, pk[sl], msg[sl], sig[sl], debug=True)
+            bad["accept_small_calls"] += int((a1 != (flags[sl] & 1)).sum()) + int((a2 != (flags[sl] & 1)).sum())
+            bad["status_small_calls"] += int((g2["status"] != odbg["status"][sl]).sum())
+            bad["norm_small_calls"] += int((g2["norm_exact"] != odbg["norm_exact"][sl]).sum())
+            c0 += m
+            k += 1
         for k, c in zip(*np.unique(kinds, return_counts=True)):
             classes[int(k)] = classes.get(int(k), 0) + int(c)
         done += n
