@@ -58,6 +58,21 @@ __global__ __launch_bounds__(64) void front_tiny_kernel(const Rows sig, const ui
     hash_wave_body(blockIdx.x - count, sig, msg, msg_off, mlen, idx, nblk, hraw);
 }
 
+// The two halves of front_tiny_kernel on their own, for the batched operators (fa_hash_to_point_many, fa_decode_sigs)
+// when they are called with a handful of items.
+__global__ __launch_bounds__(64) void hash_tiny_kernel(const Rows sig, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ msg,
+                                                       const uint64_t* __restrict__ msg_off, uint32_t mlen, uint32_t nblk,
+                                                       uint64_t* __restrict__ hraw)
+{
+  hash_wave_body(blockIdx.x, sig, msg, msg_off, mlen, idx, nblk, hraw);
+}
+template <int LOGN>
+__global__ __launch_bounds__(64) void decode_tiny_kernel(const Rows sig, uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn,
+                                                         uint8_t* __restrict__ st, uint32_t spec)
+{
+  decode_wave_body<LOGN>(blockIdx.x, sig, nullptr, s2, sqn, st, spec);
+}
+
 // ---- mixed batches (fa_verify_mixed_dev): order-preserving split of the item indices by N ----
 // logn[i] in {9, 10}. Pass 1 counts the Falcon-512 items of every run of PART_ITEMS items, pass 2 (one
 // workgroup) turns the counts into exclusive prefix sums and leaves the totals, pass 3 writes the item
@@ -886,8 +901,11 @@ int hash_to_point_dev(fa_ctx* ctx, size_t count, const uint8_t* salt, const uint
     int r = ctx->hraw.reserve((size_t)slots * nblk * 136);
     if (r) return r;
     r = timed(ctx, s, 1, [&] {
-      hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, rows_, msg_, off_, mlen,
-                         idx, slots, (const uint32_t*)nullptr, nblk, (uint64_t*)ctx->hraw.p);
+      if (slots <= ctx->tiny_batch)  // one sponge per wave: a third of the latency (tiny_kernel.hpp)
+        hipLaunchKernelGGL(hash_tiny_kernel, dim3(slots), dim3(64), 0, s, rows_, idx, msg_, off_, mlen, nblk, (uint64_t*)ctx->hraw.p);
+      else
+        hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, rows_, msg_, off_, mlen,
+                           idx, slots, (const uint32_t*)nullptr, nblk, (uint64_t*)ctx->hraw.p);
     });
     if (r) return r;
     const uint32_t grid = stride_grid(ctx, sample_kernel<LOGN>, (slots + VERIFY_WAVES - 1) / VERIFY_WAVES);
@@ -951,7 +969,15 @@ int decode_sigs_dev(fa_ctx* ctx, size_t count, const uint8_t* sig, uint8_t* salt
   if (rc) return rc;
   for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
     const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
-    rc = decode_stage<LOGN>(ctx, ws, s, slots, Rows{ sig + c0 * SIGLEN, nullptr, (uint32_t)SIGLEN }, nullptr, false);
+    const Rows rows{ sig + c0 * SIGLEN, nullptr, (uint32_t)SIGLEN };
+    if (slots <= ctx->tiny_batch) {  // one decoder wave per signature (tiny_kernel.hpp)
+      rc = timed(ctx, s, 0, [&] {
+        hipLaunchKernelGGL(decode_tiny_kernel<LOGN>, dim3(slots), dim3(64), 0, s, rows, ws.s2, ws.sqn, ws.st2,
+                           (uint32_t)(ctx->wire == FA_WIRE_SPEC));
+      });
+    } else {
+      rc = decode_stage<LOGN>(ctx, ws, s, slots, rows, nullptr, false);
+    }
     if (rc) return rc;
     const uint32_t grid = std::min<uint32_t>((slots + 3) / 4, (uint32_t)ctx->num_cu * 16u);
     hipLaunchKernelGGL(untile_sig_kernel<LOGN>, dim3(grid), dim3(256), 0, s, sig + c0 * SIGLEN, (const uint16_t*)ws.s2,

@@ -250,11 +250,16 @@ def test_hash_to_point_many(oracle, logn):
     want = np.stack([oracle.hash_to_point(logn, salt[i], msgs[i])[0] for i in range(len(lens))])
     c = capi.Context(0)
     try:
-        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)
+        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)  # one sponge per wave at this size
+        c.set_option(capi.OPT_TINY_BATCH_ITEMS, 0)
+        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)  # one sponge per lane
         c.set_option(capi.OPT_HASH_BLOCKS_512 if logn == 9 else capi.OPT_HASH_BLOCKS_1024, 8 if logn == 9 else 16)
         c.set_option(capi.OPT_CHUNK_ITEMS, 64)
-        np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)
-        assert c.get_profile()["retried_items"] > 0
+        for tiny in (0, 512):
+            c.set_option(capi.OPT_TINY_BATCH_ITEMS, tiny)
+            c.get_profile()
+            np.testing.assert_array_equal(c.hash_to_point_many(logn, salt, flat, msg_off=off), want)
+            assert c.get_profile()["retried_items"] > 0
         fixed = np.stack([m for m in msgs if m.size == 32])
         np.testing.assert_array_equal(c.hash_to_point_many(logn, salt[np.array(lens) == 32], fixed), want[np.array(lens) == 32])
     finally:
