@@ -39,6 +39,9 @@ namespace fa {
 //          v_bitop3 (b0 ^ (~b1 & b2));
 //   iota:  lanes 0 and 32.
 // The per-lane fetch addresses and shift amounts are constants of the lane: KeccakLane, built at compile time.
+// Tried and dropped: ONE round trip a round (chi operands fetched before theta, theta applied to the fetched halves from
+// four parity fetches per operand: 18 ds_bpermute, 38 instructions) -- 60 us instead of 48 for the one-item call; a
+// lone wave pays about 14 cycles to issue a ds_bpermute and only about 50 for the trip, so the count matters more.
 // ------------------------------------------------------------------------------------------------
 struct KeccakLane {
   uint8_t cm, cp, cpp;        // lanes holding C[x-1] (own half), C[x+1] (own half), C[x+1] (other half)
