@@ -11,6 +11,7 @@
 // the accept flags of verify_many<N> over the keys prepared from the decoded polynomials, a sixth those of the single-call
 // decoded-key verify<N>(h, msg, mlen, sig) on the first min(count, 8) items.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -60,6 +61,15 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     std::putchar(ok ? '1' : '0');
   }
   std::putchar('\n');
+  {  // what one call costs from C++ (stderr: information for the log, not compared): the reference's own benchmark
+     // shape, one falcon::verify<N> per signature (benchmarks/bench_verification.cpp)
+    const auto t0 = std::chrono::steady_clock::now();
+    constexpr int REPS = 200;
+    unsigned good = 0;
+    for (int r = 0; r < REPS; r++) good += falcon::verify<N>(pk.data(), msg.data(), mlen, sig.data()) ? 1u : 0u;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / REPS;
+    std::fprintf(stderr, "[host_api_check] falcon::verify<%zu>, one signature per call: %.1f us per call (%u of %d true)\n", N, us, good, REPS);
+  }
   stage("prepared keys");
   {  // decoded-key form: keys prepared once, item i against key i
     auto keys = falcon::prepared_keys<N>::from_encoded(count, pk.data());

@@ -22,6 +22,7 @@ def test_cpp_verify_and_verify_many(tmp_path, oracle, corpus, logn):
     out = subprocess.run([EXE, str(logn), str(count), "32", str(tmp_path / "pk.bin"), str(tmp_path / "msg.bin"),
                           str(tmp_path / "sig.bin"), "1", str(outdir)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+    print("\n".join(l for l in out.stderr.split("\n") if "per call" in l))  # the C++ single-call latency, for the log (-s)
     many, single, prepared, sharded, decoded_keys, decoded_single = out.stdout.split("\n")[:6]
     want = "".join(str(int(f) & 1) for f in oracle.verify_many(logn, pk, msg, sig)[0])
     assert many == want
