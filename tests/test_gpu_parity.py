@@ -232,6 +232,12 @@ def test_prepared_keys_many_signatures_per_key(ctx, oracle, corpus, logn):
     acc2, gdbg2 = ctx.verify_many_prepared(logn, prep[:nkeys], msg, sig, key_idx=kidx, debug=True)
     _compare_debug(logn, want, wdbg, acc2, gdbg2)
     assert acc2[:nkeys].tolist() == (flags[:nkeys] & 1).tolist()
+    # a handful of items: the one-wave-per-item front ahead of the prepared-key kernels, with and without the index
+    for m in (1, 7, 200):
+        a3, g3 = ctx.verify_many_prepared(logn, prep[:m], msg[:m], sig[:m], debug=True)
+        _compare_debug(logn, flags[:m], odbg[:m], a3, g3)
+        a4, g4 = ctx.verify_many_prepared(logn, prep[:nkeys], msg[:m], sig[:m], key_idx=kidx[:m], debug=True)
+        _compare_debug(logn, want[:m], wdbg[:m], a4, g4)
     with pytest.raises(Exception):
         ctx.verify_many_prepared(logn, prep[:nkeys], msg, sig, key_idx=kidx + 1)  # index out of range is refused
 
