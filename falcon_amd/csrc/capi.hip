@@ -58,6 +58,48 @@ __global__ __launch_bounds__(64) void front_tiny_kernel(const Rows sig, const ui
     hash_wave_body(blockIdx.x - count, sig, msg, msg_off, mlen, idx, nblk, hraw);
 }
 
+// The device-side retry pass (retry_tail) in ONE launch: a workgroup of three waves per queued item -- wave 0 decodes
+// the signature, wave 1 squeezes the (doubled) SHAKE256 blocks, both with an item spread over the lanes of a wave
+// (tiny_kernel.hpp), and behind a barrier wave 2 runs the verify kernel's own item code on what they left in the
+// workspace. The pass is launched behind every asynchronous and allocation-free call and almost always finds its
+// queue empty (*A.dcount == 0): one launch that exits at once instead of three. (As the front of ordinary small calls
+// the same arrangement gains nothing over front_tiny_kernel + verify_kernel)
+struct TinyFront {  // what waves 0 and 1 need beyond VerifyArgs: the inputs, and the workspace as writable pointers
+  Rows sig;
+  const uint8_t* msg;
+  const uint64_t* msg_off;
+  uint32_t mlen, spec;
+  uint16_t* s2;
+  uint32_t* sqn;
+  uint8_t* st;
+  uint64_t* hraw;
+};
+template <int LOGN, bool DEBUG, bool PREPARED>
+__global__ __launch_bounds__(192) void retry_item_kernel(const VerifyArgs<LOGN> A, const TinyFront F)
+{
+  using G = Geo<LOGN>;
+  __shared__ TwLds<LOGN> s_tw;
+  __shared__ uint32_t s_buf[G::XBUF];
+  __shared__ uint16_t s_c[G::N];
+  const uint32_t slot = blockIdx.x;
+  const uint32_t count = A.dcount ? min(A.count, *A.dcount) : A.count;
+  if (slot >= count) return;  // workgroup-uniform, ahead of every barrier
+  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);  // all three waves; ends in a workgroup barrier
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (wave == 0)  // wave-uniform
+    decode_wave_body<LOGN>(slot, F.sig, A.idx, F.s2, F.sqn, F.st, F.spec);
+  else if (wave == 1)
+    hash_wave_body(slot, F.sig, F.msg, F.msg_off, F.mlen, A.idx, A.nblk, F.hraw);
+  // Rows of neighbouring slots share cache lines (s2 tiles, hraw rows), and another workgroup on this CU may have pulled
+  // such a line into the vector cache before this one's writes: the writers release to L2, the reader invalidates.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (wave == 2) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    verify_items<LOGN, DEBUG, PREPARED, true>(A, make_tabs<LOGN>(s_tw, A.nc, lane), s_buf, s_c, lane, slot, gridDim.x, count);
+  }
+}
+
 // The two halves of front_tiny_kernel on their own, for the batched operators (fa_hash_to_point_many, fa_decode_sigs)
 // when they are called with a handful of items.
 __global__ __launch_bounds__(64) void hash_tiny_kernel(const Rows sig, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ msg,
@@ -176,7 +218,7 @@ __global__ void retry_account_kernel(uint32_t* __restrict__ ctl, uint32_t tail_c
   const uint32_t r = ctl[0];
   if (r > tail_cap) u += r - tail_cap;
   ctl[2] = u;
-  if (total && u) atomicAdd(total, u);
+  if (total && u) __hip_atomic_fetch_add(total, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // host memory (fa_ctx::h_ctl)
 }
 
 }  // namespace fa
@@ -434,7 +476,7 @@ struct fa_ctx {
   // pipeline workspace (per chunk)
   DevBuf hraw, s2, sqn, st2, ctl, retry_list, slow_list, retry2_list;
   DevBuf part_list, part_runs;  // mixed batches: the item indices split by N, per-run counts + totals
-  uint32_t* d_unresolved = nullptr;  // running total of unresolved items of asynchronous calls (256-byte block)
+  uint32_t* d_unresolved = nullptr;  // running total of unresolved items of asynchronous calls: word 16 of the GPU-mapped host block h_ctl, as the GPU sees it
   uint32_t* h_word = nullptr;        // pinned host words for small device-to-host reads
   uint32_t* h_ctl = nullptr;         // pinned, GPU-mapped host word: the re-hash counter of synchronising calls (Workspace::host_counter)
   uint32_t* d_hctl = nullptr;        // the GPU's address of it
@@ -693,9 +735,12 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
   if (slots > ws.cap_slots || (size_t)slots * nblk * 136 > ws.hraw_bytes) return FA_E_INTERNAL;
   const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC);
   const bool small = !retry && slots <= ctx->small_batch;  // does not fill the GPU: latency-bound
+  const bool one_launch = retry && dcount;  // the device-side retry pass: retry_item_kernel does all three stages
   const bool fork = ctx->overlap && !ctx->quiet;
-  int rc;
-  if (retry) {
+  int rc = 0;
+  if (one_launch) {
+    // nothing up front
+  } else if (retry) {
     rc = timed(ctx, s, 0, [&] {
       hipLaunchKernelGGL(decode_kernel<LOGN>, dim3((slots + DECODE_WG - 1) / DECODE_WG), dim3(DECODE_WG), 0, s, B.sig,
                          (const uint32_t*)nullptr, idx, slots, dcount, ws.s2, ws.sqn, ws.st2, spec);
@@ -706,7 +751,7 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
     rc = decode_stage<LOGN>(ctx, ws, s, slots, B.sig, idx, fork);
   }
   if (rc) return rc;
-  if (!small) {
+  if (!small && !one_launch) {
     rc = timed(ctx, s, 1, [&] {
       hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, B.sig, B.msg, B.msg_off, B.mlen,
                          idx, slots, dcount, nblk, ws.hraw);
@@ -739,6 +784,14 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
   A.item_base = item_base;
   A.half = ctx->wire == FA_WIRE_SPEC ? Q / 2u + 1u : Q / 2u;
   A.dbg = B.dbg;
+  if (one_launch) {
+    const TinyFront F{ B.sig, B.msg, B.msg_off, B.mlen, spec, ws.s2, ws.sqn, ws.st2, ws.hraw };
+    auto fused = [&](auto kernel) {
+      return timed(ctx, s, 2, [&] { hipLaunchKernelGGL(kernel, dim3(slots), dim3(192), 0, s, A, F); });
+    };
+    if (B.keys.prepared) return B.debug ? fused(retry_item_kernel<LOGN, true, true>) : fused(retry_item_kernel<LOGN, false, true>);
+    return B.debug ? fused(retry_item_kernel<LOGN, true, false>) : fused(retry_item_kernel<LOGN, false, false>);
+  }
   constexpr uint32_t VW = (uint32_t)verify_waves<LOGN>();
   const uint32_t want = (slots + VW - 1) / VW;
   auto launch = [&](auto kernel) {
@@ -864,7 +917,7 @@ int retry_tail(fa_ctx* ctx, const Workspace& ws, const Batch& B, hipStream_t s)
   if (cap == 0 || (size_t)cap * nblk * 136 > ws.hraw_bytes || ws.retry_counter != ws.ctl + CTL_RETRY) return FA_E_INTERNAL;
   int rc = run_pass<LOGN>(ctx, ws, s, cap, ws.retry_list, ws.ctl + CTL_RETRY, true, B, nblk, 0u, ws.ctl + CTL_UNRESOLVED, ws.retry2_list);
   if (rc) return rc;
-  hipLaunchKernelGGL(retry_account_kernel, dim3(1), dim3(1), 0, s, ws.ctl, cap, ctx->quiet ? (uint32_t*)nullptr : ctx->d_unresolved);
+  hipLaunchKernelGGL(retry_account_kernel, dim3(1), dim3(1), 0, s, ws.ctl, cap, ctx->quiet ? ctx->d_hctl + 32 : ctx->d_unresolved);
   return (int)hipGetLastError();
 }
 
@@ -1101,12 +1154,13 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_ws, hipEventDisableTiming);
-    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_unresolved, 256);
-    if (!rc) rc = (int)hipMemset(ctx->d_unresolved, 0, 256);
     if (!rc) rc = (int)hipHostMalloc((void**)&ctx->h_word, 64, hipHostMallocDefault);
     if (!rc) rc = (int)hipHostMalloc((void**)&ctx->h_ctl, 256, hipHostMallocMapped | hipHostMallocCoherent);
     if (!rc) rc = (int)hipHostGetDevicePointer((void**)&ctx->d_hctl, ctx->h_ctl, 0);
-    if (!rc) *ctx->h_ctl = 0u;
+    if (!rc) {
+      memset(ctx->h_ctl, 0, 256);
+      ctx->d_unresolved = ctx->d_hctl + 16;
+    }
     if (!rc) rc = scratch_address(device, &ctx->scratch);  // this device current (Guard above)
   }
   for (int t = 0; t < 2 && !rc; t++) try {
@@ -1161,7 +1215,6 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (ctx->d_twc[t]) (void)hipFree(ctx->d_twc[t]);
     if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
   }
-  if (ctx->d_unresolved) (void)hipFree(ctx->d_unresolved);
   if (ctx->h_word) (void)hipHostFree(ctx->h_word);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
   DevBuf* bufs[] = { &ctx->hraw, &ctx->s2, &ctx->sqn, &ctx->st2, &ctx->ctl, &ctx->retry_list, &ctx->slow_list, &ctx->retry2_list,
@@ -1286,10 +1339,10 @@ int fa_finish(fa_ctx* ctx, void* stream, uint64_t* unresolved)
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(ctx->h_word, ctx->d_unresolved, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemsetAsync(ctx->d_unresolved, 0, 256, s));
   HIP_TRY(hipStreamSynchronize(s));
-  const uint32_t n = *ctx->h_word;
+  volatile uint32_t* total = ctx->h_ctl + 16;  // written by retry_account_kernel with system-scope atomics, in host memory
+  const uint32_t n = *total;
+  *total = 0u;
   if (unresolved) *unresolved = n;
   return n ? FA_E_UNRESOLVED : 0;
 }
@@ -1346,6 +1399,8 @@ int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_
   B.policy = norm_policy;
   B.accept = accept;
   ctx->quiet = true;  // no profiling events, no second stream: nothing below allocates
+  volatile uint32_t* unresolved = ctx->h_ctl + 32;  // this call's own count, in the GPU-mapped host block (retry_tail)
+  *unresolved = 0u;
   if (logn == 9) {
     rc = verify_enqueue<9>(ctx, ws, count, nullptr, B, s);
     if (!rc) rc = retry_tail<9>(ctx, ws, B, s);
@@ -1354,12 +1409,11 @@ int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_
     if (!rc) rc = retry_tail<10>(ctx, ws, B, s);
   }
   ctx->quiet = false;
-  if (!rc) rc = (int)hipMemcpyAsync(ctx->h_word, ws.ctl + CTL_UNRESOLVED, 4, hipMemcpyDeviceToHost, s);  // into pinned memory of the context
   const int re = ws_end(ctx, s);
   if (!rc) rc = re;
   if (!rc) rc = (int)hipStreamSynchronize(s);
   if (rc) return rc;
-  return *ctx->h_word ? FA_E_UNRESOLVED : 0;
+  return *unresolved ? FA_E_UNRESOLVED : 0;
 }
 
 int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, const uint32_t* key_idx,

@@ -575,28 +575,18 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
 // GENERAL: key records through A.pk's offset array and a device-side slot count (mixed batches, the device-side retry
 // pass). A template parameter rather than a run-time test because the two extra pointers cost the main instantiation its
 // fifth wave per SIMD (82 -> 101 VGPRs, scalar registers spilling to vector lanes: +11 % cycles, measured).
+// The work of one wave: slots slot, slot + nwaves, ... below count. buf: this wave's transpose buffer (G::XBUF dwords; the
+// key row is staged in it before the first transpose), cbuf: its N hash-to-point coefficients, T: the twiddle tables.
+// A function of its own so that retry_item_kernel (capi.hip) can run it behind a decoder wave and a sponge wave in the
+// same launch.
 template <int LOGN, bool DEBUG, bool PREPARED, bool GENERAL>
-__global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const VerifyArgs<LOGN> A)
+__device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const TwTabs& T, uint32_t* __restrict__ buf,
+                                             uint16_t* __restrict__ cbuf, uint32_t lane, uint32_t slot, uint32_t nwaves, uint32_t count)
 {
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
-  constexpr int VW = verify_waves<LOGN>();
-  __shared__ TwLds<LOGN> s_tw;
-  __shared__ uint32_t s_buf[VW][G::XBUF];  // transposes; the key row is staged in it before the first one
-  __shared__ uint16_t s_c[VW][N];
   static_assert(G::PKDW * 64 <= G::XBUF, "the key row fits the transpose buffer");
-
-  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);
-
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t* buf = s_buf[wave];
   uint32_t* pkb = buf;  // same wave, LDS operations of a wave complete in order: the fields are read before buf is rewritten
-  uint16_t* cbuf = s_c[wave];
-  const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
-  const uint32_t nwaves = gridDim.x * VW;
-
-  uint32_t slot = blockIdx.x * VW + wave;
-  const uint32_t count = GENERAL && A.dcount ? min(A.count, *A.dcount) : A.count;
   if (slot >= count) return;
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED, GENERAL>(A, slot, lane, cur);
@@ -762,6 +752,21 @@ __global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const
     if (!more) break;
     slot = nslot;
   }
+}
+
+template <int LOGN, bool DEBUG, bool PREPARED, bool GENERAL>
+__global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const VerifyArgs<LOGN> A)
+{
+  using G = Geo<LOGN>;
+  constexpr int VW = verify_waves<LOGN>();
+  __shared__ TwLds<LOGN> s_tw;
+  __shared__ uint32_t s_buf[VW][G::XBUF];  // transposes
+  __shared__ uint16_t s_c[VW][G::N];
+  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
+  const uint32_t count = GENERAL && A.dcount ? min(A.count, *A.dcount) : A.count;
+  verify_items<LOGN, DEBUG, PREPARED, GENERAL>(A, T, s_buf[wave], s_c[wave], lane, blockIdx.x * VW + wave, gridDim.x * VW, count);
 }
 
 // ---- standalone hash_to_point (hashing.hpp:16-50): the rejection-sampling half on its own ----
