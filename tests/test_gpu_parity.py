@@ -452,6 +452,72 @@ def test_decode_pkeys_and_sigs(ctx, oracle, corpus, logn):
 
 
 @pytest.mark.parametrize("logn", [9, 10])
+def test_decoders_on_crafted_bodies(ctx, oracle, logn):
+    """Bodies built to stress the code-boundary search of all three decoders (wave-parallel, lane-per-item fast path,
+    generic): constant bytes, sparse and dense random bits (long zero runs = k >= 8 windows, decoding.hpp:300-320),
+    maximum-length codes up to the last bits, a code ending exactly on the last bit (decoding.hpp:340), one-bit
+    perturbations of valid bodies. ok flags and s2 identical to the oracle for every front."""
+    from falcon_amd import capi
+    n, slen = 1 << logn, support.sig_len(logn)
+    rng = np.random.default_rng(1000 + logn)
+    body = slen - 41
+    sigs = []
+
+    def with_body(b):
+        s = np.zeros(slen, np.uint8)
+        s[0] = 0x30 | logn
+        s[1:41] = rng.integers(0, 256, 40, dtype=np.uint8)
+        s[41:] = b
+        sigs.append(s)
+
+    for byte in (0x00, 0xFF, 0xAA, 0x55, 0x01, 0x80, 0x7F, 0xFE):
+        with_body(np.full(body, byte, np.uint8))
+    for density in (0.02, 0.05, 0.1, 0.2, 0.35, 0.5, 0.65, 0.8, 0.95):
+        for _ in range(6):
+            with_body(np.packbits(rng.random(body * 8) < density).astype(np.uint8))
+    budget = 8 * body
+    for big in (0, 1, n // 8, n // 4, n // 2):  # `big` coefficients with seven unary zeros each, the rest small
+        for _ in range(4):
+            s2 = rng.integers(-127, 128, n).astype(np.int32)
+            idx = rng.choice(n, big, replace=False)
+            s2[idx] = rng.choice([-1, 1], big) * rng.integers(7 * 128, 8 * 128, big)
+            ok, sg = oracle.compress_sig(logn, s2)
+            with_body(sg[41:])
+    # fill the body exactly: small coefficients are 9 bits each, every 128 more in magnitude one bit more
+    for slack in (0, 1, 2, 9):
+        s2 = np.zeros(n, np.int32)
+        extra = budget - 9 * n - slack  # unary zeros to hand out, at most 7 per coefficient
+        k = np.minimum(7, np.maximum(0, extra - 7 * np.arange(n)))
+        s2 = (k * 128 + 1).astype(np.int32)
+        ok, sg = oracle.compress_sig(logn, s2)
+        with_body(sg[41:] if ok else np.zeros(body, np.uint8))
+    base = [s.copy() for s in sigs[-24:-4]]
+    for s in base:  # one flipped bit in a valid body
+        t = s.copy()
+        bit = int(rng.integers(0, 8 * body))
+        t[41 + bit // 8] ^= 0x80 >> (bit % 8)
+        sigs.append(t)
+    sig = np.stack(sigs)
+    want_ok, want_s2 = [], []
+    for srow in sig:
+        o, _, s2o = oracle.decode_sig(logn, srow)
+        want_ok.append(o)
+        want_s2.append(s2o if o else np.zeros(n, np.int32))
+    want_ok, want_s2 = np.array(want_ok), np.stack(want_s2)
+    assert want_ok.any() and not want_ok.all()
+    c = capi.Context(0)
+    try:
+        for tiny, chunk in ((512, 1 << 20), (0, 1 << 20), (512, 64)):  # wave-parallel; fast path + generic fix-up; wave-parallel in several passes
+            c.set_option(capi.OPT_TINY_BATCH_ITEMS, tiny)
+            c.set_option(capi.OPT_CHUNK_ITEMS, chunk)
+            _, s2, ok = c.decode_sigs(logn, sig)
+            np.testing.assert_array_equal(ok.astype(bool), want_ok)
+            np.testing.assert_array_equal(s2.astype(np.int32), want_s2)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("logn", [9, 10])
 def test_reference_output_fixture(ctx, logn):
     """tests/golden/ref_outputs.npz: what the reference's own code returns for the inputs of corpus_small.npz
     (tests/golden/make_ref_golden.py). The HIP operators and the verify path's debug outputs must equal them."""
