@@ -248,7 +248,7 @@ def test_hash_to_point_many(oracle, logn):
     context with too few squeeze blocks exercises the re-hash pass."""
     from falcon_amd import capi
     rng = np.random.default_rng(logn)
-    lens = [0, 1, 32, 95, 96, 135, 136, 137, 500, 1024] * 13
+    lens = [0, 1, 32, 95, 96, 97, 135, 136, 137, 231, 232, 233, 500, 1024] * 10  # 40 + len crosses 136 at 96, 272 at 232
     salt = rng.integers(0, 256, (len(lens), 40), dtype=np.uint8)
     msgs = [rng.integers(0, 256, m, dtype=np.uint8) for m in lens]
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
