@@ -62,7 +62,7 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
   }
   std::putchar('\n');
   {  // what one call costs from C++ (stderr: information for the log, not compared): the reference's own benchmark
-     // shape, one falcon::verify<N> per signature (benchmarks/bench_verification.cpp)
+     // shape, one falcon::verify<N> per signature (benchmarks/bench_verify.cpp)
     const auto t0 = std::chrono::steady_clock::now();
     constexpr int REPS = 200;
     unsigned good = 0;
