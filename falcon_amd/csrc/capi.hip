@@ -42,20 +42,26 @@ __global__ __launch_bounds__(64) void front_small_kernel(uint32_t nd, const Rows
     hash_body<64>(blockIdx.x - nd, sig, msg, msg_off, mlen, idx, count, dcount, nblk, hraw);
 }
 
-// A handful of items (FA_OPT_TINY_BATCH_ITEMS): one decoder WAVE and one hash WAVE per item (tiny_kernel.hpp); the
-// first `count` workgroups decode, the rest hash. No fix-up queue: a signature the wave-parallel decoder cannot take
-// is decoded by the generic decoder inside the same wave.
+// A handful of items (FA_OPT_TINY_BATCH_ITEMS): one decoder WAVE and one hash WAVE per item (tiny_kernel.hpp), the two
+// waves of a 128-thread workgroup -- so that the decoder's LDS tables (21 / 41 KB) are counted once per item, not also
+// for a separate hash workgroup, and twice as many items fit the GPU at once. No fix-up queue: a signature the
+// wave-parallel decoder cannot take is decoded by the generic decoder inside the same wave.
+// `split` (passes of at most 128 items, which leave most CUs idle anyway): decoder and sponge in workgroups of their
+// own, 64 threads each, the first `split` workgroups decoding -- on different CUs the two do not share an LDS, which a
+// lone Falcon-1024 item notices (82 against 87 us).
 template <int LOGN>
-__global__ __launch_bounds__(64) void front_tiny_kernel(const Rows sig, const uint32_t* __restrict__ idx, uint32_t count,
-                                                        uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn, uint8_t* __restrict__ st,
-                                                        uint32_t spec, const uint8_t* __restrict__ msg,
-                                                        const uint64_t* __restrict__ msg_off, uint32_t mlen, uint32_t nblk,
-                                                        uint64_t* __restrict__ hraw)
+__global__ __launch_bounds__(128) void front_tiny_kernel(const Rows sig, const uint32_t* __restrict__ idx, uint32_t split,
+                                                         uint16_t* __restrict__ s2, uint32_t* __restrict__ sqn, uint8_t* __restrict__ st,
+                                                         uint32_t spec, const uint8_t* __restrict__ msg,
+                                                         const uint64_t* __restrict__ msg_off, uint32_t mlen, uint32_t nblk,
+                                                         uint64_t* __restrict__ hraw)
 {
-  if (blockIdx.x < count)  // workgroup-uniform
-    decode_wave_body<LOGN>(blockIdx.x, sig, idx, s2, sqn, st, spec);
+  const bool decoder = split ? blockIdx.x < split : threadIdx.x < 64u;  // wave-uniform
+  const uint32_t slot = split && !decoder ? blockIdx.x - split : blockIdx.x;
+  if (decoder)
+    decode_wave_body<LOGN>(slot, sig, idx, s2, sqn, st, spec);
   else
-    hash_wave_body(blockIdx.x - count, sig, msg, msg_off, mlen, idx, nblk, hraw);
+    hash_wave_body(slot, sig, msg, msg_off, mlen, idx, nblk, hraw);
 }
 
 // The device-side retry pass (retry_tail) in ONE launch: a workgroup of three waves per queued item -- wave 0 decodes
@@ -493,7 +499,8 @@ struct fa_ctx {
   std::vector<hipEvent_t> ev_free;  // events ready for reuse (no hipEventCreate inside a timed loop)
   uint32_t retried = 0;
   uint32_t small_batch = 1u << 15;  // passes of at most this many items run decoder and hash waves in one kernel (front_small_kernel)
-  uint32_t tiny_batch = 512;        // of those, passes of at most this many items run one wave per item (FA_OPT_TINY_BATCH_ITEMS)
+  uint32_t tiny_batch = 1024;       // of those, passes of at most this many Falcon-512 items (half as many Falcon-1024 items: twice the LDS) run one wave per item (FA_OPT_TINY_BATCH_ITEMS)
+  uint32_t tiny_limit(int logn) const { return logn == 9 ? tiny_batch : tiny_batch / 2u; }
   uint32_t pair_hash = 1u << 14;    // of those, passes of at most this many items hash with one sponge per lane pair (FA_OPT_PAIR_HASH_ITEMS)
   uint32_t grid_per_cu = 0;  // workgroups per CU of the grid-stride kernels (FA_OPT_GRID_PER_CU); 0: GRID_ROUNDS x what the GPU holds at once
   struct Resident {
@@ -704,10 +711,11 @@ template <int LOGN>
 int front_small(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, const uint32_t* idx, const Batch& B, uint32_t nblk)
 {
   const uint32_t spec = (uint32_t)(ctx->wire == FA_WIRE_SPEC), nd = (slots + 63) / 64;
-  if (slots <= ctx->tiny_batch)  // one wave per item and stage, no fix-up pass
+  if (slots <= ctx->tiny_limit(LOGN))  // one wave per item and stage, no fix-up pass
     return timed(ctx, s, 1, [&] {
-      hipLaunchKernelGGL(front_tiny_kernel<LOGN>, dim3(2 * slots), dim3(64), 0, s, B.sig, idx, slots, ws.s2, ws.sqn, ws.st2, spec, B.msg,
-                         B.msg_off, B.mlen, nblk, ws.hraw);
+      const uint32_t split = slots <= 128u ? slots : 0u;
+      hipLaunchKernelGGL(front_tiny_kernel<LOGN>, dim3(split ? 2u * slots : slots), dim3(split ? 64 : 128), 0, s, B.sig, idx, split, ws.s2,
+                         ws.sqn, ws.st2, spec, B.msg, B.msg_off, B.mlen, nblk, ws.hraw);
     });
   const uint32_t pair = slots <= ctx->pair_hash ? 1u : 0u, nh = pair ? (slots + 31) / 32 : nd;
   HIP_TRY(hipMemsetAsync(ws.slow_count, 0, 256, s));
@@ -954,7 +962,7 @@ int hash_to_point_dev(fa_ctx* ctx, size_t count, const uint8_t* salt, const uint
     int r = ctx->hraw.reserve((size_t)slots * nblk * 136);
     if (r) return r;
     r = timed(ctx, s, 1, [&] {
-      if (slots <= ctx->tiny_batch)  // one sponge per wave: a third of the latency (tiny_kernel.hpp)
+      if (slots <= ctx->tiny_limit(LOGN))  // one sponge per wave: a third of the latency (tiny_kernel.hpp)
         hipLaunchKernelGGL(hash_tiny_kernel, dim3(slots), dim3(64), 0, s, rows_, idx, msg_, off_, mlen, nblk, (uint64_t*)ctx->hraw.p);
       else
         hipLaunchKernelGGL(hash_kernel, dim3((slots + HASH_WG - 1) / HASH_WG), dim3(HASH_WG), 0, s, rows_, msg_, off_, mlen,
@@ -1023,7 +1031,7 @@ int decode_sigs_dev(fa_ctx* ctx, size_t count, const uint8_t* sig, uint8_t* salt
   for (size_t c0 = 0; c0 < count; c0 += ctx->chunk) {
     const uint32_t slots = (uint32_t)std::min<size_t>(ctx->chunk, count - c0);
     const Rows rows{ sig + c0 * SIGLEN, nullptr, (uint32_t)SIGLEN };
-    if (slots <= ctx->tiny_batch) {  // one decoder wave per signature (tiny_kernel.hpp)
+    if (slots <= ctx->tiny_limit(LOGN)) {  // one decoder wave per signature (tiny_kernel.hpp)
       rc = timed(ctx, s, 0, [&] {
         hipLaunchKernelGGL(decode_tiny_kernel<LOGN>, dim3(slots), dim3(64), 0, s, rows, ws.s2, ws.sqn, ws.st2,
                            (uint32_t)(ctx->wire == FA_WIRE_SPEC));
@@ -1583,7 +1591,7 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   // kernels read in place over the host link (a few KB per item, read once), and the accept bytes are written there
   // too: no copy engine, one synchronisation. One Falcon-512 item: 98 -> about 55 us per call.
   constexpr size_t ZC_MAX_BYTES = 2u << 20;
-  if (!prepared && !dbg && count <= ctx->tiny_batch) {
+  if (!prepared && !dbg && count <= ctx->tiny_limit(logn)) {
     auto up = [](size_t v) { return (v + 63u) & ~(size_t)63u; };
     const size_t first = msg_off ? (size_t)msg_off[0] : 0;
     const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;

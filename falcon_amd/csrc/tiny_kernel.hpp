@@ -13,7 +13,7 @@
 //     position of coefficient i is the composition of the tables named by the bits of i.
 // Both leave exactly what their lane-per-item counterparts leave in the workspace (s2 tiles, sqn, status, hraw rows),
 // so the verify kernel that follows is the same. front_tiny_kernel (capi.hip) runs one decoder wave and one hash wave
-// per item; the decoder wave (about 10 / 20 us) finishes well inside the hash wave's time. Device-resident call, one
+// per item, as the two waves of one workgroup; the decoder wave (about 10 / 20 us) finishes well inside the hash wave's time. Device-resident call, one
 // item: 48 us (Falcon-512), 82 us (Falcon-1024) against 102 / 162 for the lane-per-item front; ahead of it up to about
 // 1,024 (512) items a pass, where the decoder's LDS tables (21 / 41 KB a wave) limit how many waves a CU holds.
 #pragma once

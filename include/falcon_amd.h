@@ -65,7 +65,7 @@ extern "C" {
 #define FA_OPT_SMALL_BATCH_ITEMS 10 /* passes of at most this many items run decoder and hash waves in one kernel (latency), default 2^15; 0: never */
 #define FA_OPT_GRID_PER_CU 9     /* workgroups per CU of the one-wave-per-item kernels; 0 (default): 12 x what the GPU holds at once */
 #define FA_OPT_PAIR_HASH_ITEMS 12 /* of the small passes, those of at most this many items hash with one SHAKE256 sponge per lane pair (lower latency, half the items per wave), default 2^14; 0: never */
-#define FA_OPT_TINY_BATCH_ITEMS 13 /* small passes of at most this many items decode and hash with one WAVE per item (lowest latency), default 512; 0: never */
+#define FA_OPT_TINY_BATCH_ITEMS 13 /* small passes of at most this many Falcon-512 items (half as many Falcon-1024 items) decode and hash with one WAVE per item (lowest latency), default 1024; 0: never */
 #define FA_OPT_ASYNC 11          /* 1: the device-resident verify calls return without synchronising their stream, see fa_finish; default 0 */
 
 /* Wire format of public keys and signatures, for every entry point that parses them (verify, prepare_keys from

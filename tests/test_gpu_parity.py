@@ -149,12 +149,13 @@ def test_front_end_paths_and_grids(oracle, corpus, logn):
 
 @pytest.mark.parametrize("logn", [9, 10])
 def test_tiny_batches_every_count(ctx, oracle, corpus, logn):
-    """Counts 1..65 and 512 (the last size of the one-wave-per-item front) with every fourth item malformed:
+    """Counts 1..65 and 1024 / 512 (the last size of the one-wave-per-item front) with every fourth item malformed:
     decoded signature, hash-to-point, s1, norm and status identical to the oracle (falcon.hpp:230-249 one item at a
     time is the case this path exists for)."""
-    pk, msg, sig, _ = corpus.generate(logn, 512, seed=900 + logn, malformed_permille=250)
+    last = 1024 if logn == 9 else 512
+    pk, msg, sig, _ = corpus.generate(logn, last, seed=900 + logn, malformed_permille=250)
     flags, odbg = oracle.verify_many(logn, pk, msg, sig, debug=True, threads=8)
-    for n in list(range(1, 66)) + [512]:
+    for n in list(range(1, 66)) + [last]:
         acc, gdbg = ctx.verify_many(logn, pk[:n], msg[:n], sig[:n], debug=True)
         _compare_debug(logn, flags[:n], odbg[:n], acc, gdbg)
 
