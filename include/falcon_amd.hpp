@@ -30,10 +30,16 @@
 //
 // A context (device tables + workspace) is created per (thread, device) on first use, so the
 // functions are safe to call concurrently from any number of threads, as the reference's are
-// (verify_many_sharded, whose worker threads live for one call, uses one shared context per device).
+// (verify_many_sharded, whose worker threads live for one call, uses one shared context per device, and so do
+// concurrent single verify<N> calls, which are combined into batches: detail::call_combiner).
 #pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <deque>
 #include <exception>
 #include <stdexcept>
 #include <mutex>
@@ -115,6 +121,11 @@ struct shared_context {
   std::mutex lock;
   fa_ctx* ctx = nullptr;
 };
+inline int& thread_wire_flag()
+{
+  thread_local int flag = FA_WIRE_REFERENCE;
+  return flag;
+}
 inline shared_context& shared_context_for(int device)
 {
   constexpr int MAX_DEVICES = 64;
@@ -133,6 +144,7 @@ inline void set_wire_format(wire_format w, int device = 0)
 {
   const int rc = fa_set_option(detail::context(device), FA_OPT_WIRE_FORMAT, (int)w);
   if (rc) throw device_error("fa_set_option", rc);
+  detail::thread_wire_flag() = (int)w;  // single calls of this thread are combined with other threads' only in the default format
 }
 
 // Record sizes, utils.hpp:9-17 and :39-49.
@@ -365,12 +377,165 @@ inline void compress_sigs(size_t count, const int16_t* s2, uint8_t* sigs, uint8_
   if (rc) throw device_error("fa_compress_sigs", rc);
 }
 
-// falcon.hpp:230-249. `sig` is non-const there too (never written).
+namespace detail {
+
+// Single calls from many host threads at once. One falcon::verify<N> costs the GPU path about 50 us whatever else is
+// going on, and calls issued concurrently through contexts of their own queue up behind each other in the runtime
+// (measured: 8 threads, 33,000 calls a second in all, 240 us each). A call of up to a thousand items costs about the
+// same 50-60 us as a call of one, so concurrent callers are COMBINED: a caller appends its request to a queue; if no
+// batch is in flight it becomes the leader, takes what is queued (its own request included), runs it as ONE
+// fa_verify_many call on the process-wide context of device 0 and hands the results out; callers that arrive meanwhile
+// wait, and the first of them to wake leads the next batch. Alone, a thread pays a mutex and a 2 KB copy on top of the
+// call it would have made anyway. No counterpart in the reference (its verify is a pure function on the calling core).
+template<size_t N>
+class call_combiner
+{
+public:
+  static call_combiner& instance()
+  {
+    static call_combiner* const c = new call_combiner;  // kept until the process ends, like the shared contexts
+    return *c;
+  }
+
+  bool verify(const uint8_t* pkey, const uint8_t* msg, uint32_t mlen, const uint8_t* sig)
+  {
+    request r{ pkey, msg, mlen, sig, 0, 0, { false } };
+    lock();
+    pending_.push_back(&r);
+    bool lead = !busy_.load(std::memory_order_relaxed);
+    if (lead) busy_.store(true, std::memory_order_relaxed);
+    unlock();
+    while (!lead) {
+      // Wait for the result or for the leader's place. A batch takes 50-100 us, a sleeping thread about as long to be
+      // woken: watch the two flags for a while, then poll at intervals.
+      const auto t0 = std::chrono::steady_clock::now();
+      while (!r.done.load(std::memory_order_acquire) && busy_.load(std::memory_order_acquire)) {
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400))
+          relax();
+        else
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+      if (r.done.load(std::memory_order_acquire)) break;  // served: leaves without touching the queue again
+      lock();
+      lead = !r.done.load(std::memory_order_acquire) && !busy_.load(std::memory_order_relaxed);
+      if (lead) busy_.store(true, std::memory_order_relaxed);
+      unlock();
+    }
+    if (lead) {  // batches until this thread's own request has been served (normally the first one taken)
+      while (!r.done.load(std::memory_order_relaxed)) {
+        if (last_batch_ > 1) {  // callers served by the previous batch are about to come back: give them a few microseconds
+          const auto t0 = std::chrono::steady_clock::now();
+          while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(5)) relax();
+        }
+        batch_.clear();
+        size_t bytes = 0;
+        lock();
+        while (!pending_.empty() && batch_.size() < MAX_BATCH && bytes <= MAX_MSG_BYTES) {
+          bytes += pending_.front()->mlen;
+          batch_.push_back(pending_.front());
+          pending_.pop_front();
+        }
+        unlock();
+        run();
+        last_batch_ = batch_.size();
+        for (request* q : batch_) q->done.store(true, std::memory_order_release);  // *q may be gone right after this store
+      }
+      busy_.store(false, std::memory_order_release);  // a waiter whose request is still queued takes over
+    }
+    if (r.rc) throw device_error("fa_verify_many", r.rc);
+    return r.ok != 0;
+  }
+
+  // batches run and requests served so far (diagnostics)
+  void stats(uint64_t* batches, uint64_t* requests, double* run_us = nullptr) const
+  {
+    *batches = batches_, *requests = requests_;
+    if (run_us) *run_us = run_us_;
+  }
+
+private:
+  struct request {
+    const uint8_t* pkey;
+    const uint8_t* msg;
+    uint32_t mlen;
+    const uint8_t* sig;
+    uint8_t ok;
+    int rc;
+    std::atomic<bool> done;
+  };
+  static constexpr size_t MAX_BATCH = 256, MAX_MSG_BYTES = 1u << 19;
+  static void relax()
+  {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+
+  void run() noexcept  // leader only, queue lock released: batch_ and the gather buffers belong to the leader
+  {
+    int rc = 0;
+    const size_t n = batch_.size();
+    batches_++, requests_ += n;
+    const auto t_run = std::chrono::steady_clock::now();
+    try {
+      pk_.resize(n * pkey_len_), sig_.resize(n * sig_len_), off_.resize(n + 1), acc_.assign(n, 0);
+      size_t total = 0;
+      for (size_t i = 0; i < n; i++) off_[i] = total, total += batch_[i]->mlen;
+      off_[n] = total;
+      msg_.resize(total + 8);
+      for (size_t i = 0; i < n; i++) {
+        std::memcpy(pk_.data() + i * pkey_len_, batch_[i]->pkey, pkey_len_);
+        std::memcpy(sig_.data() + i * sig_len_, batch_[i]->sig, sig_len_);
+        if (batch_[i]->mlen) std::memcpy(msg_.data() + off_[i], batch_[i]->msg, batch_[i]->mlen);
+      }
+      shared_context& sc = shared_context_for(0);
+      std::lock_guard<std::mutex> hold(sc.lock);
+      if (!sc.ctx) rc = fa_ctx_create(0, &sc.ctx);
+      if (!rc) rc = fa_set_option(sc.ctx, FA_OPT_WIRE_FORMAT, FA_WIRE_REFERENCE);
+      if (!rc)
+        rc = fa_verify_many(sc.ctx, logn<N>(), n, pk_.data(), msg_.data(), off_.data(), 0, sig_.data(), FA_NORM_EXACT64, acc_.data(), nullptr);
+    } catch (...) {
+      rc = FA_E_INTERNAL;
+    }
+    for (size_t i = 0; i < n; i++) batch_[i]->ok = rc ? 0 : acc_[i], batch_[i]->rc = rc;
+    run_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run).count();
+  }
+
+  static constexpr size_t pkey_len_ = 1 + 14 * N / 8, sig_len_ = N == 512 ? 666 : 1280;
+  // the queue's lock is held for a push or a drain, a fraction of a microsecond: a spin lock, because eight threads
+  // meeting at a std::mutex put each other to sleep for longer than a whole batch takes
+  void lock()
+  {
+    while (qlock_.test_and_set(std::memory_order_acquire)) relax();
+  }
+  void unlock() { qlock_.clear(std::memory_order_release); }
+  std::atomic_flag qlock_ = ATOMIC_FLAG_INIT;
+  std::deque<request*> pending_;
+  std::atomic<bool> busy_{ false };
+  std::vector<request*> batch_;
+  std::vector<uint8_t> pk_, sig_, msg_, acc_;
+  std::vector<uint64_t> off_;
+  uint64_t batches_ = 0, requests_ = 0;
+  double run_us_ = 0;  // time spent inside run()
+  size_t last_batch_ = 0;  // size of the previous batch: more than one means other threads are calling too
+};
+
+}  // namespace detail
+
+// falcon.hpp:230-249. `sig` is non-const there too (never written). Calls made by several threads at the same time
+// are combined into one batch (detail::call_combiner) unless FALCON_AMD_NO_CALL_COMBINING is defined or the calling
+// thread has chosen the specification wire format.
 template<size_t N>
 static inline bool verify(const uint8_t* __restrict pkey, const uint8_t* __restrict msg, const size_t mlen,
                           uint8_t* __restrict sig)
   requires((N == 512) || (N == 1024))
 {
+#ifndef FALCON_AMD_NO_CALL_COMBINING
+  if (detail::thread_wire_flag() == FA_WIRE_REFERENCE)
+    return detail::call_combiner<N>::instance().verify(pkey, msg, detail::msg_len(mlen), sig);
+#endif
   uint8_t ok = 0;
   verify_many<N>(1, pkey, msg, mlen, nullptr, sig, &ok);
   return ok != 0;

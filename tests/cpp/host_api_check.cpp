@@ -11,6 +11,7 @@
 // the accept flags of verify_many<N> over the keys prepared from the decoded polynomials, a sixth those of the single-call
 // decoded-key verify<N>(h, msg, mlen, sig) on the first min(count, 8) items.
 #include <algorithm>
+#include <barrier>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include <iostream>
 #include <iterator>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "falcon_amd.hpp"
@@ -69,6 +71,43 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     for (int r = 0; r < REPS; r++) good += falcon::verify<N>(pk.data(), msg.data(), mlen, sig.data()) ? 1u : 0u;
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / REPS;
     std::fprintf(stderr, "[host_api_check] falcon::verify<%zu>, one signature per call: %.1f us per call (%u of %d true)\n", N, us, good, REPS);
+  }
+  {  // the same from several host threads at once, each with its own context (falcon_amd.hpp keeps one per thread and device)
+    constexpr int THREADS = 8, CALLS = 100;
+    std::vector<std::thread> pool;
+    std::vector<unsigned> good(THREADS, 0);
+    std::vector<size_t> pick;  // eight accepted items (a malformed one may take the slow decoder: not what is being timed)
+    for (size_t i = 0; i < count && pick.size() < 8; i++)
+      if (acc[i]) pick.push_back(i);
+    if (pick.empty()) pick.push_back(0);
+    const size_t span = pick.size();
+    uint64_t b0 = 0, q0 = 0, b1 = 0, q1 = 0;
+    double u0 = 0, u1 = 0;
+    std::barrier ready(THREADS + 1);
+    for (int t = 0; t < THREADS; t++)
+      pool.emplace_back([&, t] {
+        (void)falcon::verify<N>(pk.data(), msg.data(), mlen, sig.data());  // creates this thread's context
+        ready.arrive_and_wait();
+        for (int r = 0; r < CALLS; r++) {
+          const size_t i = pick[(size_t)(t + r) % span];
+          const bool ok = falcon::verify<N>(pk.data() + i * falcon::pkey_len<N>(), msg.data() + i * mlen, mlen, sig.data() + i * falcon::sig_len<N>());
+          good[(size_t)t] += ok == (acc[i] != 0) ? 1u : 0u;
+        }
+      });
+    ready.arrive_and_wait();
+    falcon::detail::call_combiner<N>::instance().stats(&b0, &q0, &u0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (auto& th : pool) th.join();
+    falcon::detail::call_combiner<N>::instance().stats(&b1, &q1, &u1);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    unsigned agree = 0;
+    for (unsigned g : good) agree += g;
+    std::fprintf(stderr, "[host_api_check] falcon::verify<%zu> from %d threads: %.0f calls per second in all, per call %.1f us, %.1f calls per batch, %.1f us per batch of which %.1f in the library call\n", N,
+                 THREADS, THREADS * CALLS / sec, sec / CALLS * 1e6, (double)(q1 - q0) / (double)(b1 - b0), sec * 1e6 / (double)(b1 - b0), (u1 - u0) / (double)(b1 - b0));
+    if (agree != THREADS * CALLS) {
+      std::fprintf(stderr, "concurrent single calls disagree with the batch: %u of %d\n", agree, THREADS * CALLS);
+      return 3;
+    }
   }
   stage("prepared keys");
   {  // decoded-key form: keys prepared once, item i against key i
