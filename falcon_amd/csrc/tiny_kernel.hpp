@@ -149,15 +149,16 @@ __device__ __forceinline__ void hash_wave_body(uint32_t slot, const Rows& sig, c
 // ------------------------------------------------------------------------------------------------
 // Compressed-signature decoder, one wave per signature (decoding.hpp:267-361; the rules are decode_kernel.hpp's).
 //   1. The body (bytes 41..) goes to LDS as big-endian dwords, zero beyond its end.
-//   2. For EVERY bit position p: J[p] = p + 9 + k(p), the position after a code that starts at p (k = zeros in the
-//      8-bit window behind the 8 head bits, 8 if there is no 1 in it), clamped to a last position that maps to itself.
+//   2. For EVERY bit position p: J[p] = the position after a code that starts at p: p + 9 + k(p) (k = zeros in the 8-bit
+//      window behind the 8 head bits) or, when the window holds no 1, where the reference's window rule lands; clamped
+//      to a last position that maps to itself.
 //   3. LOGN - 1 times: J <- J o J (two tables, ping-pong). Before each doubling, every lane moves the cursors of its
 //      coefficients i = lane + 64 m whose bit j is set through the table of level j: jumps by powers of the same
 //      function commute, so after LOGN levels cursor i is next^i(0).
-//   4. Every lane decodes its coefficients at their cursors. A code with k = 8 anywhere (the reference's window rule,
-//      the specification's long runs, or a code that reaches into the padding) sends the item to the generic
-//      decoder, run by lane 0 on the spot. Otherwise: "-0" or a last code ending at or beyond the last bit fail
-//      (decoding.hpp:327-330, 340), and the bits behind the last code must be zero (decoding.hpp:342-357).
+//   4. Every lane decodes its coefficients at their cursors. "-0" or a last code ending at or beyond the last bit fail
+//      (decoding.hpp:327-330, 340), and the bits behind the last code must be zero (decoding.hpp:342-357). A code whose
+//      run of empty windows is longer than eight, and in specification mode any k = 8 code, sends the item to the
+//      generic decoder, run by lane 0 on the spot (about 90 us).
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 struct DecodeWaveGeo {
@@ -200,13 +201,42 @@ __device__ __forceinline__ void decode_wave_body(uint32_t slot, const Rows& sig,
     return (uint32_t)(((((uint64_t)image[d] << 32) | image[d + 1u]) << (p & 31u)) >> 32);
   };
 
+  // The position behind a code that starts at p and has no 1 in its window (k = 8), by the reference's rule
+  // (decoding.hpp:300-320, 335): whole 8-bit windows are skipped until one holds a 1 or the stream ends, then one more
+  // bit. Up to eight windows are followed here; a longer run, and the specification's different rule, answer SLOW --
+  // a second position that maps to itself, "a code here needs the generic decoder".
+  constexpr uint32_t SLOW = NPOS - 2u;
+  int32_t last_one = -1;  // position of the last 1 of the body: behind it every window is empty and a run ends at the end of the stream
+  for (uint32_t d = lane; d < NPOS / 32u; d += 64u)
+    if (image[d]) last_one = max(last_one, (int32_t)(32u * d + 31u - (uint32_t)__builtin_ctz(image[d])));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) last_one = max(last_one, __shfl_xor(last_one, o));
+  auto jump8 = [&](uint32_t p) -> uint32_t {
+    if (spec) return SLOW;
+    uint32_t q = p + 16u;
+    if ((int32_t)q > last_one) return BITS + 1u;  // nothing but zeros from q on: the scan stops at the end, then the extra bit
+    bool found = false;
+#pragma unroll 1
+    for (int it = 0; it < 8 && q < BITS && !found; it++) {
+      const uint32_t e = min(8u, BITS - q);
+      found = (window(q) >> (32u - e)) != 0u;
+      q += e;
+    }
+    return !found && q < BITS ? SLOW : min(q + 1u, LAST);
+  };
+
   // 2. level 0: two neighbouring positions per lane and step, so that a table dword is written whole
   for (uint32_t q = lane; q < NPOS / 2u; q += 64u) {
     const uint32_t d = q >> 4;
     const uint64_t bits = (((uint64_t)image[d] << 32) | image[d + 1u]) << ((2u * q) & 31u);  // >= 33 valid bits
     const uint32_t w0 = (uint32_t)(bits >> 32), w1 = (uint32_t)(bits >> 31);
     const uint32_t k0 = (uint32_t)__builtin_clz((w0 << 8) | 0x00800000u), k1 = (uint32_t)__builtin_clz((w1 << 8) | 0x00800000u);
-    const uint32_t j0 = min(2u * q + 9u + k0, LAST), j1 = min(2u * q + 10u + k1, LAST);
+    uint32_t j0 = min(2u * q + 9u + k0, LAST), j1 = min(2u * q + 10u + k1, LAST);
+    if (k0 == 8u) j0 = jump8(2u * q);
+    if (k1 == 8u) j1 = jump8(2u * q + 1u);
+    if (2u * q >= BITS) j0 = LAST;       // a code that would start at or beyond the end: decoding stops (decoding.hpp:281) --
+    if (2u * q + 1u >= BITS) j1 = LAST;  // straight to the last position, so that SLOW is reached by a real long run only
+    if (2u * q >= SLOW) j0 = SLOW;       // SLOW and LAST map to themselves
     table[0][q] = j0 | (j1 << 16);
   }
   wave_lds_sync();
@@ -237,32 +267,29 @@ __device__ __forceinline__ void decode_wave_body(uint32_t slot, const Rows& sig,
   }
 
   // 4. coefficients
-  uint32_t norm = 0u, maxk = 0u, maxv = 0u, endpos = 0u;
+  uint32_t norm = 0u, maxv = 0u, endpos = 0u;
+  bool slow = false;
   uint32_t val[PER];
 #pragma unroll
   for (uint32_t m = 0; m < PER; m++) {
     const uint32_t top = window(cur[m]);
     const uint32_t k = (uint32_t)__builtin_clz((top << 8) | 0x00800000u);
-    const uint32_t mag = ((top >> 24) & 0x7fu) + (k << 7);
+    const uint32_t mag = ((top >> 24) & 0x7fu) + (k < 8u ? k << 7 : 0u);  // a k = 8 code keeps its low 7 bits only (decoding.hpp:300-320)
     const uint32_t neg = (uint32_t)((int32_t)top >> 31);
     val[m] = (mag ^ neg) + (neg & (Q + 1u));  // sign ? q - mag : mag (verification.hpp:36-39)
     norm += mag * mag;
-    maxk = max(maxk, k);
     maxv = max(maxv, val[m]);
-    if (m == PER - 1u) endpos = cur[m] + 9u + k;  // lane 63: the position behind the last code
+    slow |= cur[m] == SLOW || (k == 8u && spec != 0u);
+    if (m == PER - 1u) endpos = k < 8u ? cur[m] + 9u + k : jump8(cur[m]);  // lane 63: the position behind the last code
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     norm += __shfl_xor(norm, o);
-    maxk = max(maxk, __shfl_xor(maxk, o));
     maxv = max(maxv, __shfl_xor(maxv, o));
   }
   endpos = __shfl(endpos, 63);
 
-#ifdef FA_TINY_FORCE_GENERIC
-  maxk = 8u;
-#endif
-  if (maxk >= 8u) {  // wave-uniform: the rare shapes go through the generic decoder, every rule in one place
+  if (__ballot(slow) != 0ull || endpos == SLOW) {  // wave-uniform: the rare shapes go through the generic decoder, every rule in one place
     // The row pointer is wave-uniform here, and left to itself hipcc turns the generic decoder's 16-byte loads into
     // scalar loads whose immediate offset (41) and base are each unaligned with an aligned sum -- the scalar unit drops
     // the low two bits of every address component on its own and reads the wrong dwords (seen on gfx950: every item
@@ -270,7 +297,7 @@ __device__ __forceinline__ void decode_wave_body(uint32_t slot, const Rows& sig,
     if (lane == 0) decode_generic_item<LOGN>(row + __builtin_amdgcn_mbcnt_lo(0u, 0u), slot, s2, sqn, st, spec);
     return;
   }
-  // every code is regular (a 1 inside its window, hence inside the body): endpos <= BITS, no clamp was hit
+  // a cursor at or beyond the end of the body leaves endpos there too (positions only grow): decoding.hpp:281, 340
   bool failed = (spec ? endpos > BITS : endpos >= BITS) || maxv == Q;
   uint32_t tail = 0u;  // bits behind the last code
   for (uint32_t d = lane; d < NPOS / 32u; d += 64u) {
