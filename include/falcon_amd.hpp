@@ -550,6 +550,24 @@ static inline bool verify(const uint16_t* __restrict h, const uint8_t* __restric
                           const uint8_t* __restrict sig, int device = 0)
   requires((N == 512) || (N == 1024))
 {
+  // A polynomial whose coefficients fit 14 bits is exactly what decode_pkey (decoding.hpp:34-45) yields from the key
+  // packed the obvious way, and the packed path takes raw fields as they are: pack it on the stack (a microsecond) and
+  // make the ordinary single call -- one round trip, combinable with other threads' calls -- instead of preparing a key
+  // on the GPU, copying it back and verifying against it (three round trips).
+  bool fits = device == 0;
+  for (size_t i = 0; i < N && fits; i++) fits = h[i] < 16384u;
+  if (fits) {
+    uint8_t pk[pkey_len<N>()] = {};
+    pk[0] = (uint8_t)detail::logn<N>();
+    for (size_t i = 0; i < N; i++) {  // coefficient i at bit 14 i behind the header byte, least significant bit first
+      const size_t bit = 14 * i;
+      const uint32_t v = (uint32_t)h[i] << (bit & 7);
+      pk[1 + (bit >> 3)] |= (uint8_t)v;
+      pk[2 + (bit >> 3)] |= (uint8_t)(v >> 8);
+      if ((bit & 7) > 2) pk[3 + (bit >> 3)] |= (uint8_t)(v >> 16);
+    }
+    return verify<N>(pk, msg, mlen, const_cast<uint8_t*>(sig));
+  }
   const prepared_keys<N> key = prepared_keys<N>::from_decoded(1, h, device);
   uint8_t ok = 0;
   verify_many<N>(1, key, nullptr, msg, mlen, nullptr, sig, &ok, device);

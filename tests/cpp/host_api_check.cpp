@@ -182,6 +182,25 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     for (size_t i = 0; i < count && i < 8; i++)
       std::putchar(falcon::verify<N>(h.data() + i * N, msg.data() + i * mlen, mlen, sig.data() + i * falcon::sig_len<N>()) ? '1' : '0');
     std::putchar('\n');
+    {  // its cost (stderr, information)
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned good = 0;
+      for (int r = 0; r < 200; r++) good += falcon::verify<N>(h.data(), msg.data(), mlen, sig.data()) ? 1u : 0u;
+      std::fprintf(stderr, "[host_api_check] falcon::verify<%zu>(h, ...), decoded key, one signature per call: %.1f us per call (%u of 200 true)\n", N,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 200, good);
+    }
+    {  // a coefficient that does not fit 14 bits takes the prepared-key route: same answer as the batch form gives
+      std::vector<uint16_t> big(h.begin(), h.begin() + N);
+      big[3] = (uint16_t)(big[3] % 12289u + 2u * 12289u);  // same residue mod q, 24,578 or more
+      auto k1 = falcon::prepared_keys<N>::from_decoded(1, big.data());
+      uint8_t want = 7;
+      falcon::verify_many<N>(1, k1, nullptr, msg.data(), mlen, nullptr, sig.data(), &want);
+      const bool got = falcon::verify<N>(big.data(), msg.data(), mlen, sig.data());
+      if (got != (want != 0) || got != (acc5[0] != 0)) {
+        std::fprintf(stderr, "verify(h, ...) with a coefficient >= 2^14 differs\n");
+        return 7;
+      }
+    }
   }
   stage("done");
   return 0;
