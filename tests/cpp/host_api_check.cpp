@@ -11,6 +11,7 @@
 // the accept flags of verify_many<N> over the keys prepared from the decoded polynomials, a sixth those of the single-call
 // decoded-key verify<N>(h, msg, mlen, sig) on the first min(count, 8) items.
 #include <algorithm>
+#include <atomic>
 #include <barrier>
 #include <chrono>
 #include <cstdio>
@@ -106,6 +107,23 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
                  THREADS, THREADS * CALLS / sec, sec / CALLS * 1e6, (double)(q1 - q0) / (double)(b1 - b0), sec * 1e6 / (double)(b1 - b0), (u1 - u0) / (double)(b1 - b0));
     if (agree != THREADS * CALLS) {
       std::fprintf(stderr, "concurrent single calls disagree with the batch: %u of %d\n", agree, THREADS * CALLS);
+      return 3;
+    }
+    // and 16 threads over every kind of item the corpus holds (rejected ones included), different messages lengths apart
+    std::vector<std::thread> more;
+    std::atomic<unsigned> wrong{ 0 };
+    const size_t items = count < 64 ? count : 64;
+    for (int t = 0; t < 16; t++)
+      more.emplace_back([&, t] {
+        for (int r = 0; r < 60; r++) {
+          const size_t i = (size_t)(7 * t + 13 * r) % items;
+          const bool ok = falcon::verify<N>(pk.data() + i * falcon::pkey_len<N>(), msg.data() + i * mlen, mlen, sig.data() + i * falcon::sig_len<N>());
+          if (ok != (acc[i] != 0)) wrong++;
+        }
+      });
+    for (auto& th : more) th.join();
+    if (wrong.load()) {
+      std::fprintf(stderr, "16 threads, mixed items: %u single calls disagree with the batch\n", wrong.load());
       return 3;
     }
   }
