@@ -28,7 +28,9 @@ EXPORTS = ["fa_ctx_create", "fa_ctx_destroy", "fa_set_option", "fa_get_profile",
            "fa_compute_public_keys_dev", "fa_host_alloc", "fa_host_free", "fa_host_register", "fa_host_unregister",
            "fa_ntt_many", "fa_ntt_many_dev", "fa_decode_pkeys", "fa_decode_pkeys_dev", "fa_decode_sigs", "fa_decode_sigs_dev",
            "fa_finish", "fa_verify_many_dev_noalloc", "fa_verify_mixed_dev",
-           "fa_encode_pkeys", "fa_encode_pkeys_dev", "fa_compress_sigs", "fa_compress_sigs_dev"]
+           "fa_encode_pkeys", "fa_encode_pkeys_dev", "fa_compress_sigs", "fa_compress_sigs_dev",
+           "fa_keyset_create", "fa_keyset_destroy", "fa_keyset_size", "fa_keyset_logn", "fa_keyset_device_keys",
+           "fa_verify_many_keyset"]
 
 
 class FaDebug(ctypes.Structure):
@@ -83,6 +85,15 @@ def load_library():
     lib.fa_prepare_keys_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp]
     lib.fa_verify_many_prepared.argtypes = [vp, i32, sz, vp, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug)]
     lib.fa_verify_many_prepared_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug), vp]
+    lib.fa_keyset_create.argtypes = [vp, i32, sz, vp, vp, ctypes.POINTER(vp)]
+    lib.fa_keyset_destroy.argtypes = [vp]
+    lib.fa_keyset_destroy.restype = None
+    lib.fa_keyset_size.argtypes = [vp]
+    lib.fa_keyset_size.restype = sz
+    lib.fa_keyset_logn.argtypes = [vp]
+    lib.fa_keyset_device_keys.argtypes = [vp]
+    lib.fa_keyset_device_keys.restype = vp
+    lib.fa_verify_many_keyset.argtypes = [vp, vp, sz, vp, vp, vp, u32, vp, i32, vp, ctypes.POINTER(FaDebug)]
     lib.fa_hash_to_point_many.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp]
     lib.fa_hash_to_point_many_dev.argtypes = [vp, i32, sz, vp, vp, vp, u32, vp, vp]
     lib.fa_compute_public_keys.argtypes = [vp, i32, sz, vp, vp, vp]
@@ -154,6 +165,36 @@ class PinnedArray:
             self.array = None
             self.lib.fa_host_free(self.ptr)
             self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Keyset:
+    """A set of public keys resident on one GPU in prepared form (fa_keyset); close() frees it."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def __len__(self):
+        return int(self.lib.fa_keyset_size(self.handle))
+
+    @property
+    def logn(self):
+        return int(self.lib.fa_keyset_logn(self.handle))
+
+    @property
+    def device_ptr(self):
+        """Device address of the prepared keys (for verify_many_prepared_dev)."""
+        return self.lib.fa_keyset_device_keys(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.fa_keyset_destroy(self.handle)
+            self.handle = None
 
     def __del__(self):
         try:
@@ -283,6 +324,48 @@ class Context:
                                               _ptr(off), mlen, _ptr(sig), norm_policy, _ptr(accept),
                                               ctypes.byref(dbg) if dbg is not None else None)
         _check(rc, "fa_verify_many_prepared")
+        return (accept, out) if debug else accept
+
+    def keyset_create(self, logn, pk=None, h=None):
+        """fa_keyset_create: the keys stay on the GPU (prepared form); returns a Keyset."""
+        if (pk is None) == (h is None):
+            raise ValueError("give exactly one of pk, h")
+        src = np.ascontiguousarray(pk, np.uint8) if pk is not None else np.ascontiguousarray(h, np.uint16)
+        nkeys = src.shape[0]
+        want = self.lib.fa_pkey_len(logn) if pk is not None else (1 << logn)
+        if src.ndim != 2 or src.shape != (nkeys, want):
+            raise ValueError("key array shape does not match logn")
+        out = ctypes.c_void_p()
+        rc = self.lib.fa_keyset_create(self.handle, logn, nkeys, _ptr(src) if pk is not None else None,
+                                       _ptr(src) if pk is None else None, ctypes.byref(out))
+        _check(rc, "fa_keyset_create")
+        return Keyset(self.lib, out)
+
+    def verify_many_keyset(self, keyset, msg, sig, key_idx=None, msg_off=None, norm_policy=NORM_EXACT64, debug=False,
+                           accept_out=None):
+        """fa_verify_many_keyset: host arrays of signatures, messages and key indices against a resident Keyset."""
+        logn = keyset.logn
+        n = 1 << logn
+        sig = np.ascontiguousarray(sig, np.uint8)
+        count = sig.shape[0]
+        if sig.shape != (count, self.lib.fa_sig_len(logn)):
+            raise ValueError("sig shape does not match the key set's logn")
+        kidx = None if key_idx is None else np.ascontiguousarray(key_idx, np.uint32)
+        if kidx is not None and kidx.shape != (count,):
+            raise ValueError("key_idx must hold count entries")
+        msg, off, mlen, mp = self._msg_args(msg, msg_off, count)
+        accept = np.zeros(count, np.uint8) if accept_out is None else accept_out
+        if accept.dtype != np.uint8 or accept.shape != (count,) or not accept.flags.c_contiguous:
+            raise ValueError("accept_out must be a contiguous (count,) uint8 array")
+        dbg = out = None
+        if debug:
+            out = {"c": np.zeros((count, n), np.uint16), "s2": np.zeros((count, n), np.int16),
+                   "s1": np.zeros((count, n), np.int16), "norm_exact": np.zeros(count, np.uint64),
+                   "norm_wrap32": np.zeros(count, np.uint32), "status": np.zeros(count, np.uint8)}
+            dbg = FaDebug(*[_ptr(out[k]) for k, _ in FaDebug._fields_])
+        rc = self.lib.fa_verify_many_keyset(self.handle, keyset.handle, count, _ptr(kidx), mp, _ptr(off), mlen, _ptr(sig),
+                                            norm_policy, _ptr(accept), ctypes.byref(dbg) if dbg is not None else None)
+        _check(rc, "fa_verify_many_keyset")
         return (accept, out) if debug else accept
 
     def hash_to_point_many(self, logn, salt, msg, msg_off=None):

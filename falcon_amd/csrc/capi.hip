@@ -90,7 +90,7 @@ __global__ __launch_bounds__(192) void retry_item_kernel(const VerifyArgs<LOGN> 
   const uint32_t slot = blockIdx.x;
   const uint32_t count = A.dcount ? min(A.count, *A.dcount) : A.count;
   if (slot >= count) return;  // workgroup-uniform, ahead of every barrier
-  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);  // all three waves; ends in a workgroup barrier
+  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.isc);  // all three waves; ends in a workgroup barrier
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (wave == 0)  // wave-uniform
     decode_wave_body<LOGN>(slot, F.sig, A.idx, F.s2, F.sqn, F.st, F.spec);
@@ -231,10 +231,15 @@ __global__ void retry_account_kernel(uint32_t* __restrict__ ctl, uint32_t tail_c
 
 using namespace fa;
 
+// A failing runtime call is reported through the return value; it must not linger as the runtime's "last error",
+// where the hipGetLastError() behind a later, good launch would find it.
 #define HIP_TRY(expr)                      \
   do {                                     \
     const hipError_t e_ = (expr);          \
-    if (e_ != hipSuccess) return (int)e_;  \
+    if (e_ != hipSuccess) {                \
+      (void)hipGetLastError();             \
+      return (int)e_;                      \
+    }                                      \
   } while (0)
 
 namespace {
@@ -253,19 +258,11 @@ uint32_t bitrev(uint32_t v, int bits)
   for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
   return r;
 }
-// centred twiddle and its Shoup companion round(w * 2^32 / q), zq.hpp
-Tw make_tw(uint32_t w)
-{
-  const int64_t wc = w > Q / 2 ? (int64_t)w - (int64_t)Q : (int64_t)w;
-  const int64_t num = 2 * (wc * ((int64_t)1 << 32)) + (int64_t)Q, den = 2 * (int64_t)Q;
-  int64_t wp = num / den;
-  if (num % den < 0) wp--;  // floor division
-  return Tw{ (int32_t)wc, (int32_t)wp };
-}
-
 struct Tables {
-  std::vector<Tw> fwd, inv;    // reference order, ntt.hpp:62-83
-  std::vector<Tw> fwdC, invC;  // phase-C layout [lane][TWC], verify_kernel.hpp
+  std::vector<Tw> fwd;   // forward twiddles zeta^bitrev(k), reference order (ntt.hpp:62-83), Plantard form (zq.hpp)
+  std::vector<Tw> fwdC;  // the same in the phase-C layout [lane][TWC], verify_kernel.hpp
+  std::vector<Tw> inv;   // inverse (decimation in time): entry 2^b + j = omega^-(N/2^(b+1) * j), omega = zeta^2
+  std::vector<Tw> isc;   // inverse scaling: entry p = zeta^-p / N (ntt.hpp:25-29 folded in)
   NttConsts nc;
 };
 Tables make_tables(int logn)
@@ -273,34 +270,24 @@ Tables make_tables(int logn)
   const uint32_t n = 1u << logn, zeta = logn == 9 ? 49u : 7u;  // ntt.hpp:18,23
   Tables t;
   t.fwd.resize(n);
-  t.inv.resize(n);
-  uint32_t inv1 = 1;  // canonical inverse twiddle of index 1
-  for (uint32_t k = 0; k < n; k++) {
-    const uint32_t w = powmod(zeta, bitrev(k, logn)), wi = powmod(w, Q - 2);
-    t.fwd[k] = make_tw(w);
-    t.inv[k] = make_tw(wi);
-    if (k == 1) inv1 = wi;
-  }
-  const uint32_t ninv = powmod(n, Q - 2);  // ntt.hpp:25-29
-  t.nc.ninv = make_tw(ninv);
-  t.nc.inv_last = make_tw(inv1 * ninv % Q);
-  for (int k = 0; k < 16; k++) {
-    t.nc.twA[k] = t.fwd[k];
-    t.nc.itwA[k] = t.inv[k];
-  }
+  for (uint32_t k = 0; k < n; k++) t.fwd[k] = plant_const(powmod(zeta, bitrev(k, logn)));
+  const uint32_t zinv = powmod(zeta, Q - 2), oinv = zinv * zinv % Q, ninv = powmod(n, Q - 2);
+  t.inv.assign(n, 0u);
+  for (int b = 0; b < logn; b++)
+    for (uint32_t j = 0; j < (1u << b); j++) t.inv[(1u << b) + j] = plant_const(powmod(oinv, (n >> (b + 1)) * j));
+  t.isc.resize(n);
+  for (uint32_t p = 0; p < n; p++) t.isc[p] = plant_const(powmod(zinv, p) * ninv % Q);
+  for (int k = 0; k < 16; k++) t.nc.twA[k] = t.fwd[k];
+  for (int k = 0; k < 8; k++) t.nc.itwA[k] = t.inv[k];
   // phase C: registers hold index bits [0, LB); the stage on bit lb uses, for lane L, the entries
   // (N >> (lb+1)) + (L << (LB-1-lb)) + j, j < 2^(LB-1-lb), stored consecutively in the lane's row.
   const int LB = logn - 6, PB = 6 - LB, TWC = logn == 9 ? 7 : 13;
-  t.fwdC.assign(64 * TWC, Tw{ 0, 0 });
-  t.invC.assign(64 * TWC, Tw{ 0, 0 });
+  t.fwdC.assign(64 * TWC, 0u);
   for (uint32_t lane = 0; lane < 64; lane++) {
     int e = 0;
     for (int lb = PB - 1; lb >= 0; lb--)
-      for (uint32_t j = 0; j < (1u << (LB - 1 - lb)); j++, e++) {
-        const uint32_t k = (n >> (lb + 1)) + (lane << (LB - 1 - lb)) + j;
-        t.fwdC[lane * TWC + e] = t.fwd[k];
-        t.invC[lane * TWC + e] = t.inv[k];
-      }
+      for (uint32_t j = 0; j < (1u << (LB - 1 - lb)); j++, e++)
+        t.fwdC[lane * TWC + e] = t.fwd[(n >> (lb + 1)) + (lane << (LB - 1 - lb)) + j];
   }
   return t;
 }
@@ -470,10 +457,10 @@ struct fa_ctx {
   DevBuf spec_pk;                  // FA_WIRE_SPEC: the batch's keys repacked into the reference's form
   bool overlap = true;
   bool async = false;              // FA_OPT_ASYNC: device-resident verify calls return without synchronising
-  Tw* d_tw[2] = { nullptr, nullptr };
+  Tw* d_tw[2] = { nullptr, nullptr };   // the four tables of make_tables, per N
   Tw* d_itw[2] = { nullptr, nullptr };
   Tw* d_twc[2] = { nullptr, nullptr };
-  Tw* d_itwc[2] = { nullptr, nullptr };
+  Tw* d_isc[2] = { nullptr, nullptr };
   NttConsts nc[2];
   uint32_t chunk = 1u << 20;
   uint32_t hash_blocks[2] = { 9, 17 };
@@ -507,6 +494,15 @@ struct fa_ctx {
     const void* kernel;
     uint32_t per_cu;
   } resident[32] = {};  // kernel -> workgroups of VERIFY_WG threads resident per CU (asked once per kernel)
+};
+
+// A set of public keys kept on one GPU in prepared form (fa_keyset_create): what fa_verify_many_keyset and the
+// device-resident prepared-key calls read their keys from.
+struct fa_keyset {
+  int device = 0;
+  int logn = 0;
+  size_t nkeys = 0;
+  uint16_t* d_prepared = nullptr;  // nkeys * N uint16 (prepare_keys_kernel), hipMalloc'ed on `device`
 };
 
 namespace {
@@ -583,6 +579,33 @@ int ws_end(fa_ctx* ctx, hipStream_t s)
   ctx->ws_busy = true;
   return 0;
 }
+// The pair as a scope: whatever way a call leaves after begin() -- an allocation that fails, a bad tag array, a launch
+// error -- the event is recorded behind what the call did enqueue, so that the next call on another stream waits for
+// it (an early return between ws_begin and ws_end used to leave the fence at the previous call's last kernel).
+struct WsScope {
+  fa_ctx* ctx;
+  hipStream_t s;
+  bool open = false;
+  WsScope(fa_ctx* c, hipStream_t st) : ctx(c), s(st) {}
+  WsScope(const WsScope&) = delete;
+  WsScope& operator=(const WsScope&) = delete;
+  int begin()
+  {
+    const int rc = ws_begin(ctx, s);
+    open = rc == 0;
+    return rc;
+  }
+  int end()
+  {
+    if (!open) return 0;
+    open = false;
+    return ws_end(ctx, s);
+  }
+  ~WsScope()
+  {
+    if (open) (void)ws_end(ctx, s);
+  }
+};
 
 // Grid of a grid-stride kernel (one item per wave, VERIFY_WG threads per workgroup) that has `want` workgroups of
 // work. Default: GRID_ROUNDS times what the GPU holds at once. Measured (tools/grid_sweep.sh, 2^20 items): waves do
@@ -780,7 +803,7 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
   A.tw = ctx->d_tw[T];
   A.itw = ctx->d_itw[T];
   A.twc = ctx->d_twc[T];
-  A.itwc = ctx->d_itwc[T];
+  A.isc = ctx->d_isc[T];
   A.nc = ctx->nc[T];
   A.count = slots;
   A.dcount = dcount;
@@ -1012,7 +1035,7 @@ int polymul_dev(fa_ctx* ctx, size_t count, const uint16_t* a, const uint16_t* b,
     const size_t o = p0 << LOGN;
     const int rc = timed(ctx, s, 3, [&] {
       hipLaunchKernelGGL(polymul_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, a + o, b + o, c + o, n, ctx->d_tw[T],
-                         ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+                         ctx->d_itw[T], ctx->d_twc[T], ctx->d_isc[T], ctx->nc[T]);
     });
     if (rc) return rc;
   }
@@ -1072,6 +1095,7 @@ static __device__ __align__(256) unsigned char scratch[SC_BYTES];
 namespace {
 std::mutex g_scratch_lock;
 unsigned char* g_scratch_ptr[FA_MAX_DEVICES] = {};  // per device: each GPU holds its own copy of the array at its own address
+std::mutex g_scratch_use[FA_MAX_DEVICES];           // held by the call that is using that GPU's copy (fa_verify_many_dev_noalloc)
 
 // The device address of `scratch` on `device` (which must be current), asked once per device.
 int scratch_address(int device, unsigned char** out)
@@ -1181,9 +1205,9 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMemcpy(ctx->d_itw[t], tb.inv.data(), bytes, hipMemcpyHostToDevice);
     const size_t cbytes = tb.fwdC.size() * sizeof(Tw);
     if (!rc) rc = (int)hipMalloc((void**)&ctx->d_twc[t], cbytes);
-    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_itwc[t], cbytes);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_isc[t], bytes);
     if (!rc) rc = (int)hipMemcpy(ctx->d_twc[t], tb.fwdC.data(), cbytes, hipMemcpyHostToDevice);
-    if (!rc) rc = (int)hipMemcpy(ctx->d_itwc[t], tb.invC.data(), cbytes, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_isc[t], tb.isc.data(), bytes, hipMemcpyHostToDevice);
   } catch (...) {  // std::bad_alloc while building the tables
     rc = FA_E_INTERNAL;
   }
@@ -1221,7 +1245,7 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (ctx->d_tw[t]) (void)hipFree(ctx->d_tw[t]);
     if (ctx->d_itw[t]) (void)hipFree(ctx->d_itw[t]);
     if (ctx->d_twc[t]) (void)hipFree(ctx->d_twc[t]);
-    if (ctx->d_itwc[t]) (void)hipFree(ctx->d_itwc[t]);
+    if (ctx->d_isc[t]) (void)hipFree(ctx->d_isc[t]);
   }
   if (ctx->h_word) (void)hipHostFree(ctx->h_word);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
@@ -1348,9 +1372,9 @@ int fa_finish(fa_ctx* ctx, void* stream, uint64_t* unresolved)
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipStreamSynchronize(s));
-  volatile uint32_t* total = ctx->h_ctl + 16;  // written by retry_account_kernel with system-scope atomics, in host memory
-  const uint32_t n = *total;
-  *total = 0u;
+  // written by retry_account_kernel with system-scope atomics, in host memory; calls of this context on OTHER streams may
+  // still be running, so the word is taken and cleared in one step: an increment lands either in this count or in the next
+  const uint32_t n = __atomic_exchange_n(ctx->h_ctl + 16, 0u, __ATOMIC_ACQ_REL);
   if (unresolved) *unresolved = n;
   return n ? FA_E_UNRESOLVED : 0;
 }
@@ -1365,7 +1389,8 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = ws_begin(ctx, s))) return rc;
+  WsScope fence(ctx, s);
+  if ((rc = fence.begin())) return rc;
   Batch B;
   const uint8_t* pkr = pk;
   if ((rc = keys_in_reference_form(ctx, logn, s, pk, count, &pkr))) return rc;
@@ -1378,7 +1403,7 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   B.accept = accept;
   set_debug(B, dbg);
   rc = logn == 9 ? verify_dev<9>(ctx, count, nullptr, B, s) : verify_dev<10>(ctx, count, nullptr, B, s);
-  const int re = ws_end(ctx, s);
+  const int re = fence.end();
   return rc ? rc : re;
 }
 
@@ -1396,7 +1421,13 @@ int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = ws_begin(ctx, s))) return rc;
+  // Every context on this GPU carves its workspace out of the SAME array: calls through different contexts (the C++
+  // layer keeps one per host thread) would overwrite each other's s2 tiles, hash blocks and counters while kernels run.
+  // One lock per GPU, held until this call's stream synchronisation below: such calls run one after the other. An
+  // uncontended lock costs nothing and allocates nothing.
+  std::lock_guard<std::mutex> one_at_a_time(g_scratch_use[ctx->device]);
+  WsScope fence(ctx, s);
+  if ((rc = fence.begin())) return rc;
   const Workspace ws = ws_from_scratch(ctx->scratch);  // the device address, not the symbol
   Batch B;
   B.keys.pk = Rows{ pk, nullptr, (uint32_t)fa_pkey_len(logn) };
@@ -1417,9 +1448,10 @@ int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_
     if (!rc) rc = retry_tail<10>(ctx, ws, B, s);
   }
   ctx->quiet = false;
-  const int re = ws_end(ctx, s);
+  const int re = fence.end();
+  const int rs = (int)hipStreamSynchronize(s);  // also on failure: nothing of this call may still use the array when the lock goes
   if (!rc) rc = re;
-  if (!rc) rc = (int)hipStreamSynchronize(s);
+  if (!rc) rc = rs;
   if (rc) return rc;
   return *unresolved ? FA_E_UNRESOLVED : 0;
 }
@@ -1434,7 +1466,8 @@ int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint1
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = ws_begin(ctx, s))) return rc;
+  WsScope fence(ctx, s);
+  if ((rc = fence.begin())) return rc;
   Batch B;
   B.keys.prepared = prepared;
   B.keys.key_idx = key_idx;
@@ -1446,7 +1479,7 @@ int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint1
   B.accept = accept;
   set_debug(B, dbg);
   rc = logn == 9 ? verify_dev<9>(ctx, count, nullptr, B, s) : verify_dev<10>(ctx, count, nullptr, B, s);
-  const int re = ws_end(ctx, s);
+  const int re = fence.end();
   return rc ? rc : re;
 }
 
@@ -1465,7 +1498,8 @@ int fa_verify_mixed_dev(fa_ctx* ctx, size_t count, const uint8_t* logn, const ui
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if ((rc = ws_begin(ctx, s))) return rc;
+  WsScope fence(ctx, s);
+  if ((rc = fence.begin())) return rc;
   const uint32_t n = (uint32_t)count, nruns = (n + PART_ITEMS - 1) / PART_ITEMS;
   if ((rc = ctx->part_list.reserve((size_t)n * 4))) return rc;
   if ((rc = ctx->part_runs.reserve(256 + (size_t)nruns * 4))) return rc;
@@ -1480,10 +1514,7 @@ int fa_verify_mixed_dev(fa_ctx* ctx, size_t count, const uint8_t* logn, const ui
   HIP_TRY(hipMemcpyAsync(ctx->h_word, totals, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));  // the class sizes decide the passes
   const uint32_t n9 = ctx->h_word[0], bad = ctx->h_word[1];
-  if (bad || n9 > n) {
-    (void)ws_end(ctx, s);
-    return FA_E_LOGN;
-  }
+  if (bad || n9 > n) return FA_E_LOGN;
   Batch B;
   B.msg = msg;
   B.msg_off = msg_off;
@@ -1493,7 +1524,7 @@ int fa_verify_mixed_dev(fa_ctx* ctx, size_t count, const uint8_t* logn, const ui
   B.sig = Rows{ sig, sig_off, 0u };
   if (n9) rc = verify_dev<9>(ctx, n9, list, B, s);
   if (!rc && n - n9) rc = verify_dev<10>(ctx, n - n9, list + n9, B, s);
-  const int re = ws_end(ctx, s);
+  const int re = fence.end();
   return rc ? rc : re;
 }
 
@@ -1510,7 +1541,8 @@ int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, 
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  if (const int rb = ws_begin(ctx, s)) return rb;  // FA_WIRE_SPEC repacks the keys into a buffer of the context
+  WsScope fence(ctx, s);  // FA_WIRE_SPEC repacks the keys into a buffer of the context
+  if (const int rb = fence.begin()) return rb;
   const int T = logn - 9;
   const uint32_t n = (uint32_t)nkeys, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   {
@@ -1520,14 +1552,14 @@ int fa_prepare_keys_dev(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, 
 #define FA_LAUNCH_PREP(LN, PACKED)                                                                                      \
   hipLaunchKernelGGL((prepare_keys_kernel<LN, PACKED>), dim3(stride_grid(ctx, prepare_keys_kernel<LN, PACKED>, want)),   \
                      dim3(VERIFY_WG), 0, s, pk, h, n, prepared, ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T],              \
-                     ctx->d_itwc[T], ctx->nc[T])
+                     ctx->d_isc[T], ctx->nc[T])
   if (logn == 9) {
     if (pk) FA_LAUNCH_PREP(9, true); else FA_LAUNCH_PREP(9, false);
   } else {
     if (pk) FA_LAUNCH_PREP(10, true); else FA_LAUNCH_PREP(10, false);
   }
 #undef FA_LAUNCH_PREP
-  const int rl = (int)hipGetLastError(), re = ws_end(ctx, s);
+  const int rl = (int)hipGetLastError(), re = fence.end();
   return rl ? rl : re;
 }
 
@@ -1560,16 +1592,19 @@ int fa_prepare_keys(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, cons
 // pageable caller memory the copy calls block the host thread (the runtime stages them) but still overlap
 // the kernels already enqueued; with pinned memory (fa_host_alloc / fa_host_register) they are asynchronous
 // and the whole call runs at the rate of the host link.
-static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint16_t* prepared, size_t nkeys,
-                       const uint32_t* key_idx, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
+// Keys: packed, one per item (`pk`); or prepared, in caller memory (`prepared`, uploaded with the call); or prepared
+// and already resident on the GPU (`resident`, a key set): then only signatures, messages and key indices cross the link.
+static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint16_t* prepared, const uint16_t* resident,
+                       size_t nkeys, const uint32_t* key_idx, const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen,
                        const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
 {
   if (!ctx || (norm_policy != FA_NORM_EXACT64 && norm_policy != FA_NORM_WRAP32)) return FA_E_ARG;
   if (logn != 9 && logn != 10) return FA_E_LOGN;
   if (count == 0) return 0;
-  if ((!pk && !prepared) || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
+  if ((!pk && !prepared && !resident) || !sig || !accept || (!msg && (msg_off || mlen))) return FA_E_ARG;
   if (count > 0xFFFFFFFFull) return FA_E_ARG;
-  if (prepared) {  // every item must name an existing key
+  const bool keyed = prepared || resident;  // items name their key by index
+  if (keyed) {  // every item must name an existing key
     if (nkeys == 0 || nkeys > 0xFFFFFFFFull || (!key_idx && nkeys < count)) return FA_E_ARG;
     if (key_idx)
       for (size_t i = 0; i < count; i++)
@@ -1584,7 +1619,8 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
   const size_t n = (size_t)1 << logn, pklen = fa_pkey_len(logn), siglen = fa_sig_len(logn);
   hipStream_t cs = ctx->stream, xs = ctx->copy;
   int rc;
-  if ((rc = ws_begin(ctx, cs))) return rc;
+  WsScope fence(ctx, cs);
+  if ((rc = fence.begin())) return rc;
 
   // A handful of items (the one-wave-per-item front, FA_OPT_TINY_BATCH_ITEMS): three staged copies, two events and
   // the copy back cost more than the kernels take. The inputs are gathered in pinned host memory instead, which the
@@ -1595,14 +1631,16 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     auto up = [](size_t v) { return (v + 63u) & ~(size_t)63u; };
     const size_t first = msg_off ? (size_t)msg_off[0] : 0;
     const size_t msg_bytes = msg_off ? (size_t)msg_off[count] - first : count * (size_t)mlen;
-    const size_t o_pk = 0, o_sig = up(o_pk + count * pklen + 8), o_msg = up(o_sig + count * siglen + 8);
+    // packed keys, or (resident key set) the items' key indices, in the first slot
+    const size_t o_pk = 0, o_sig = up(o_pk + (resident ? (key_idx ? count * 4 : 0) : count * pklen + 8)), o_msg = up(o_sig + count * siglen + 8);
     const size_t o_off = up(o_msg + msg_bytes + 16), o_acc = up(o_off + (msg_off ? (count + 1) * 8 : 0)), total = up(o_acc + count);
     if (total <= ZC_MAX_BYTES) {
       if ((rc = ctx->zc.reserve(ZC_MAX_BYTES))) return rc;
       uint8_t* h = (uint8_t*)ctx->zc.p;
       uint8_t* d = nullptr;
       HIP_TRY(hipHostGetDevicePointer((void**)&d, h, 0));
-      memcpy(h + o_pk, pk, count * pklen);
+      if (!resident) memcpy(h + o_pk, pk, count * pklen);
+      else if (key_idx) memcpy(h + o_pk, key_idx, count * 4);
       memcpy(h + o_sig, sig, count * siglen);
       const size_t m0 = o_msg + (first & 3u);  // message bytes land at their offset modulo 4: the kernels' base stays aligned
       if (msg_bytes) memcpy(h + m0, msg + (msg_off ? first : 0), msg_bytes);
@@ -1610,12 +1648,17 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
       Batch B;
       B.policy = norm_policy;
       B.mlen = mlen;
-      B.keys.pk = Rows{ d + o_pk, nullptr, (uint32_t)pklen };
+      if (resident) {
+        B.keys.prepared = resident;
+        B.keys.key_idx = key_idx ? (const uint32_t*)(d + o_pk) : nullptr;
+      } else {
+        B.keys.pk = Rows{ d + o_pk, nullptr, (uint32_t)pklen };
+      }
       B.sig = Rows{ d + o_sig, nullptr, (uint32_t)siglen };
       B.msg = d + m0 - first;
       B.msg_off = msg_off ? (const uint64_t*)(d + o_off) : nullptr;
       B.accept = d + o_acc;
-      if (ctx->wire == FA_WIRE_SPEC && (rc = keys_in_reference_form(ctx, logn, cs, B.keys.pk.base, count, &B.keys.pk.base))) return rc;
+      if (!resident && ctx->wire == FA_WIRE_SPEC && (rc = keys_in_reference_form(ctx, logn, cs, B.keys.pk.base, count, &B.keys.pk.base))) return rc;
       Workspace ws;
       rc = logn == 9 ? ws_from_ctx<9>(ctx, (uint32_t)count, ctx->hash_blocks[0], count, ws) : ws_from_ctx<10>(ctx, (uint32_t)count, ctx->hash_blocks[1], count, ws);
       if (!rc) rc = logn == 9 ? verify_enqueue<9>(ctx, ws, count, nullptr, B, cs) : verify_enqueue<10>(ctx, ws, count, nullptr, B, cs);
@@ -1625,7 +1668,7 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     }
   }
 
-  const uint16_t* d_prepared = nullptr;
+  const uint16_t* d_prepared = resident;
   if (prepared) {  // the key table is shared by all sub-batches: staged once, ahead of the first kernel
     if ((rc = ctx->h_pk.reserve(nkeys * n * 2 + 8))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->h_pk.p, prepared, nkeys * n * 2, hipMemcpyHostToDevice, cs));
@@ -1655,7 +1698,7 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     if ((r = h2d(ctx->device, st.sig.p, sig + S.c0 * siglen, S.cnt * siglen, xs, st.pin_sig, ctx->host_threads))) return r;
     S.B.sig = Rows{ (const uint8_t*)st.sig.p, nullptr, (uint32_t)siglen };
     S.B.accept = (uint8_t*)st.accept.p;
-    if (prepared) {
+    if (keyed) {
       S.B.keys.prepared = key_idx ? d_prepared : d_prepared + S.c0 * n;  // no index: item i uses key i
       if (key_idx) {
         if ((r = st.kidx.reserve(S.cnt * 4))) return r;
@@ -1736,8 +1779,9 @@ static int verify_host(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
     if (!rc) rc = finish(cur);
     cur = nxt;
   }
+  const int re = fence.end();
   const int rs = (int)hipStreamSynchronize(xs), rt = (int)hipStreamSynchronize(cs);  // nothing of the caller's is in flight on return
-  return rc ? rc : rs ? rs : rt;
+  return rc ? rc : rs ? rs : rt ? rt : re;
 }
 
 void* fa_host_alloc(size_t bytes)
@@ -1769,7 +1813,7 @@ int fa_verify_many(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const
                    uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
 {
   if (!pk && count) return FA_E_ARG;
-  return verify_host(ctx, logn, count, pk, nullptr, 0, nullptr, msg, msg_off, mlen, sig, norm_policy, accept, dbg);
+  return verify_host(ctx, logn, count, pk, nullptr, nullptr, 0, nullptr, msg, msg_off, mlen, sig, norm_policy, accept, dbg);
 }
 
 int fa_verify_many_prepared(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, size_t nkeys,
@@ -1777,7 +1821,72 @@ int fa_verify_many_prepared(fa_ctx* ctx, int logn, size_t count, const uint16_t*
                             const uint8_t* sig, int norm_policy, uint8_t* accept, const fa_debug* dbg)
 {
   if (!prepared && count) return FA_E_ARG;
-  return verify_host(ctx, logn, count, nullptr, prepared, nkeys, key_idx, msg, msg_off, mlen, sig, norm_policy, accept, dbg);
+  return verify_host(ctx, logn, count, nullptr, prepared, nullptr, nkeys, key_idx, msg, msg_off, mlen, sig, norm_policy, accept, dbg);
+}
+
+// ---- resident key sets ----
+int fa_keyset_create(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, fa_keyset** out)
+{
+  if (!out) return FA_E_ARG;
+  *out = nullptr;
+  if (!ctx) return FA_E_ARG;
+  if (logn != 9 && logn != 10) return FA_E_LOGN;
+  if (nkeys == 0 || nkeys > 0xFFFFFFFFull || (!pk) == (!h)) return FA_E_ARG;  // exactly one of pk, h
+  Guard g(ctx->device);
+  if (g.err) return g.err;
+  fa_keyset* ks = new (std::nothrow) fa_keyset;
+  if (!ks) return FA_E_INTERNAL;
+  ks->device = ctx->device;
+  ks->logn = logn;
+  ks->nkeys = nkeys;
+  const size_t n = (size_t)1 << logn, rec = pk ? fa_pkey_len(logn) : n * 2;
+  int rc = (int)hipMalloc((void**)&ks->d_prepared, nkeys * n * 2 + 8);
+  // the keys go through the context's staging buffer in pieces, each prepared into its place in the set
+  const size_t piece = std::max<size_t>(1, std::min<size_t>(nkeys, ((size_t)64 << 20) / rec));
+  hipStream_t s = ctx->stream;
+  const uint8_t* src = pk ? pk : (const uint8_t*)h;
+  for (size_t k0 = 0; !rc && k0 < nkeys; k0 += piece) {
+    const size_t cnt = std::min(piece, nkeys - k0);
+    {
+      WsScope fence(ctx, s);  // the staging buffer belongs to the context
+      if (!rc) rc = fence.begin();
+      if (!rc) rc = ctx->h_pk.reserve(cnt * rec + 8);
+      if (!rc) rc = h2d(ctx->device, ctx->h_pk.p, src + k0 * rec, cnt * rec, s, ctx->hs[0].pin_pk, ctx->host_threads);
+    }
+    if (!rc)
+      rc = fa_prepare_keys_dev(ctx, logn, cnt, pk ? (const uint8_t*)ctx->h_pk.p : nullptr, pk ? nullptr : (const uint16_t*)ctx->h_pk.p,
+                               ks->d_prepared + k0 * n, s);
+    const int rs = (int)hipStreamSynchronize(s);  // the pinned staging piece is free again
+    if (!rc) rc = rs;
+  }
+  if (rc) {
+    fa_keyset_destroy(ks);
+    return rc;
+  }
+  *out = ks;
+  return 0;
+}
+
+void fa_keyset_destroy(fa_keyset* ks)
+{
+  if (!ks) return;
+  Guard g(ks->device);
+  if (ks->d_prepared) (void)hipFree(ks->d_prepared);  // waits for the device's work, as hipFree does
+  delete ks;
+}
+
+size_t fa_keyset_size(const fa_keyset* ks) { return ks ? ks->nkeys : 0; }
+int fa_keyset_logn(const fa_keyset* ks) { return ks ? ks->logn : 0; }
+const uint16_t* fa_keyset_device_keys(const fa_keyset* ks) { return ks ? ks->d_prepared : nullptr; }
+
+int fa_verify_many_keyset(fa_ctx* ctx, const fa_keyset* ks, size_t count, const uint32_t* key_idx, const uint8_t* msg,
+                          const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept,
+                          const fa_debug* dbg)
+{
+  if (!ctx || !ks) return FA_E_ARG;
+  if (ks->device != ctx->device) return FA_E_ARG;  // the set lives in another GPU's memory
+  return verify_host(ctx, ks->logn, count, nullptr, nullptr, ks->d_prepared, ks->nkeys, key_idx, msg, msg_off, mlen, sig, norm_policy,
+                     accept, dbg);
 }
 
 int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_t* pk, const uint64_t* pk_off,
@@ -1801,7 +1910,8 @@ int fa_verify_mixed(fa_ctx* ctx, size_t count, const uint8_t* logn, const uint8_
   if (g.err) return g.err;
   hipStream_t s = ctx->stream;
   int rc;
-  if ((rc = ws_begin(ctx, s))) return rc;
+  WsScope fence(ctx, s);  // the staging buffers belong to the context (fa_verify_mixed_dev brackets its own work again)
+  if ((rc = fence.begin())) return rc;
   if ((rc = ctx->h_pk.reserve(pk_bytes + 16))) return rc;
   if ((rc = ctx->h_sig.reserve(sig_bytes + 16))) return rc;
   if ((rc = ctx->h_msg.reserve(msg_bytes + 16))) return rc;
@@ -1841,9 +1951,10 @@ int fa_hash_to_point_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t
   if (g.err) return g.err;
   if (mlen > FA_MAX_MSG_LEN) return FA_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (const int rb = ws_begin(ctx, s)) return rb;
+  WsScope fence(ctx, s);
+  if (const int rb = fence.begin()) return rb;
   const int rc = logn == 9 ? hash_to_point_dev<9>(ctx, count, salt, msg, msg_off, mlen, c, s) : hash_to_point_dev<10>(ctx, count, salt, msg, msg_off, mlen, c, s);
-  const int re = ws_end(ctx, s);
+  const int re = fence.end();
   return rc ? rc : re;
 }
 
@@ -1897,10 +2008,10 @@ int fa_compute_public_keys_dev(fa_ctx* ctx, int logn, size_t count, const int32_
   const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   if (logn == 9)
     hipLaunchKernelGGL(pubkey_kernel<9>, dim3(stride_grid(ctx, pubkey_kernel<9>, want)), dim3(VERIFY_WG), 0, s, f, g, h, n,
-                       ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+                       ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_isc[T], ctx->nc[T]);
   else
     hipLaunchKernelGGL(pubkey_kernel<10>, dim3(stride_grid(ctx, pubkey_kernel<10>, want)), dim3(VERIFY_WG), 0, s, f, g, h, n,
-                       ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T]);
+                       ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_isc[T], ctx->nc[T]);
   return (int)hipGetLastError();
 }
 
@@ -1942,7 +2053,7 @@ int fa_ntt_many_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* a, uint
   const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
 #define FA_LAUNCH_NTT(LN, INV)                                                                                          \
   hipLaunchKernelGGL((ntt_kernel<LN, INV>), dim3(stride_grid(ctx, ntt_kernel<LN, INV>, want)), dim3(VERIFY_WG), 0, s,   \
-                     a, out, n, ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_itwc[T], ctx->nc[T])
+                     a, out, n, ctx->d_tw[T], ctx->d_itw[T], ctx->d_twc[T], ctx->d_isc[T], ctx->nc[T])
   if (logn == 9) {
     if (inverse) FA_LAUNCH_NTT(9, true); else FA_LAUNCH_NTT(9, false);
   } else {
@@ -1983,7 +2094,8 @@ int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, 
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;
-  if (const int rb = ws_begin(ctx, s)) return rb;  // FA_WIRE_SPEC repacks the keys into a buffer of the context
+  WsScope fence(ctx, s);  // FA_WIRE_SPEC repacks the keys into a buffer of the context
+  if (const int rb = fence.begin()) return rb;
   const uint32_t n = (uint32_t)count, want = (n + VERIFY_WAVES - 1) / VERIFY_WAVES;
   {
     const int rc = keys_in_reference_form(ctx, logn, s, pk, count, &pk);
@@ -1993,7 +2105,7 @@ int fa_decode_pkeys_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, 
     hipLaunchKernelGGL(decode_pkeys_kernel<9>, dim3(stride_grid(ctx, decode_pkeys_kernel<9>, want)), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
   else
     hipLaunchKernelGGL(decode_pkeys_kernel<10>, dim3(stride_grid(ctx, decode_pkeys_kernel<10>, want)), dim3(VERIFY_WG), 0, s, pk, n, h, ok);
-  const int rl = (int)hipGetLastError(), re = ws_end(ctx, s);
+  const int rl = (int)hipGetLastError(), re = fence.end();
   return rl ? rl : re;
 }
 
@@ -2031,9 +2143,10 @@ int fa_decode_sigs_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* sig, 
   Guard g(ctx->device);
   if (g.err) return g.err;
   hipStream_t s = (hipStream_t)stream;  // the decoders write the context's workspace, which the untiling kernel reads
-  if (const int rb = ws_begin(ctx, s)) return rb;
+  WsScope fence(ctx, s);
+  if (const int rb = fence.begin()) return rb;
   const int rc = logn == 9 ? decode_sigs_dev<9>(ctx, count, sig, salt, s2, ok, s) : decode_sigs_dev<10>(ctx, count, sig, salt, s2, ok, s);
-  const int re = ws_end(ctx, s);
+  const int re = fence.end();
   return rc ? rc : re;
 }
 

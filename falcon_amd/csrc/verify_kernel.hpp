@@ -6,21 +6,37 @@
 //   decoding.hpp:18-48     decode_pkey (14-bit little-endian fields, header = log2 n)
 //   ntt.hpp:120-150        forward negacyclic NTT (Cooley-Tukey, natural in, bit-reversed out)
 //   polynomial.hpp:99-110  pointwise product
-//   ntt.hpp:161-200        inverse NTT (Gentleman-Sande) with the 1/N scaling
+//   ntt.hpp:161-200        inverse NTT with the 1/N scaling
 //   verification.hpp:53-79 s1 = c - s2*h, centring, squared norm, comparison with beta^2
 // Only the coefficient-domain values c, s2, s1 and the norm are observable, so the transform
 // uses 2 forward + 1 inverse NTT (the reference runs 3 + 1, verification.hpp:47-57) and its
-// own butterfly order; all arithmetic is exact mod q, hence bit-identical results.
+// own butterflies; all arithmetic is exact mod q, hence bit-identical results.
+//
+// Both directions are built from ONE butterfly, the Cooley-Tukey one (t = w*b; b' = a - t; a' = a + t), four
+// instructions with the Plantard product of zq.hpp. The forward transform is the reference's own (ntt.hpp:120-150:
+// stages on index bits logn-1 .. 0, twiddle zeta^bitrev(k) per block). The inverse is NOT the reference's
+// Gentleman-Sande network (ntt.hpp:161-200), whose butterfly multiplies a difference -- that difference would
+// need one more instruction to stay non-negative, and its sums double per stage -- but the decimation-in-time
+// form of the same map: stages on index bits 0 .. logn-1 with the cyclic twiddles omega^-(N/2^(b+1) * (p mod 2^b)),
+// omega = zeta^2, then one multiplication per coefficient by zeta^-p / N (which also leaves the result canonical).
+// Same input order (bit-reversed), same output, same values mod q; 156 instead of 200 instructions per lane for
+// n = 512, and the forward transform 148 instead of 180.
+//
+// Values are unsigned lazy residues below 2^32/q (zq.hpp). A butterfly widens the range by q on either side, so
+// the first stage of a transform adds BIAS = logn*q to its sums' inputs once; nothing is reduced in between:
+//   forward: inputs < 2^16            ->  outputs in [0, 2^16 + 2 logn q) < 311,316
+//   inverse: inputs <= q              ->  before the final scaling in [0, (2 logn + 1) q) <= 258,069;  after it < q
 //
 // Data layout inside a wave (n = 64*R coefficients, R = 8 or 16 per lane, LB = log2 R):
 //   phase A  lane = i & 63,                     regs hold index bits [6, logn)   stages on those bits
 //   phase B  lane = (i>>6 << PB) | (i & (2^PB-1)), regs hold bits [PB, 6), PB = 6 - LB
 //   phase C  lane = i >> LB,                    regs hold bits [0, LB)
 // with two transposes through a per-wave LDS buffer in between (padded so that every
-// ds_read_b32 / ds_write_b32 is bank-conflict free). Twiddles (w, round(w 2^32/q)), indexed like the
-// reference's POWERS_OF_zeta table (ntt.hpp:62-83), come from three places: phase A's are the same
-// for every lane and arrive as kernel arguments (SGPRs); phase B's sit in a small LDS table; phase
-// C's sit in an LDS table laid out per lane (odd stride, so the ds_read_b64 are conflict free).
+// ds_read_b32 / ds_write_b32 is bank-conflict free). The forward transform runs A, B, C, the inverse C, B, A.
+// Twiddles (one dword each) come from three places. Forward: phase A's are the same for every lane and arrive as
+// kernel arguments (SGPRs); phase B's sit in a small LDS table; phase C's sit in an LDS table laid out per lane
+// (odd stride, conflict free). Inverse, mirrored: phase C's depend only on the register index (kernel arguments),
+// phase B's and A's on the lane's low index bits: consecutive lanes read consecutive dwords of one LDS table.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,10 +48,9 @@ namespace fa {
 
 constexpr int VERIFY_WAVES = 4;  // waves per workgroup
 constexpr int VERIFY_WG = 64 * VERIFY_WAVES;
-// The verify kernel itself runs Falcon-1024 in workgroups of eight waves: its LDS is 17.4 KB of twiddle tables per
-// workgroup plus 6.4 KB per wave, so four-wave workgroups (43 KB) fit a CU three times = three waves per SIMD, eight-wave
-// ones (68.6 KB) twice = four; with the single register set of the item loop the kernel needs 128 VGPRs, which is what
-// four waves per SIMD allow.
+// The verify kernel itself runs Falcon-1024 in workgroups of eight waves: its LDS is 12.3 KB of twiddle tables per
+// workgroup plus 6.4 KB per wave, so eight-wave workgroups (63.5 KB) fit a CU twice = four waves per SIMD, which is
+// what the kernel's 128 VGPRs allow (four-wave workgroups would fit only three times).
 template <int LOGN> constexpr int verify_waves() { return LOGN == 10 ? 8 : 4; }
 
 template <int LOGN>
@@ -47,10 +62,12 @@ struct Geo {
   static constexpr int PKLEN = 1 + 14 * N / 8;
   static constexpr int XBUF = N + 64;    // dwords of the padded transpose buffer
   static constexpr uint32_t BETA2 = LOGN == 9 ? 34034726u : 70265242u;  // falcon.hpp:245
-  static constexpr int TWB = N >> PB;    // phase-B twiddle indices are < N >> PB
+  static constexpr uint32_t BIAS = (uint32_t)LOGN * Q;  // added once per transform: keeps every difference non-negative
+  static constexpr int TWB = N >> PB;    // phase-B forward twiddle indices are < N >> PB
   static constexpr int TWC = LOGN == 9 ? 7 : 13;  // per-lane phase-C entries (odd stride; 7 resp. 12 used)
   static constexpr int PKDW = ((PKLEN + 6) / 4 + 63) / 64;  // aligned dwords per lane covering a key row (any alignment)
   static constexpr int MAXHW = LOGN == 9 ? 5 : 10;    // prefetched dwords of squeezed blocks per lane (9 / 17 blocks)
+  static_assert(65535u + 2u * BIAS < PLANT_LIMIT, "forward transform of any u16 input stays below 2^32/q");
 };
 
 // offset of the first phase-C table entry of the stage on register bit lb (stages run lb = PB-1 .. 0,
@@ -64,13 +81,11 @@ __host__ __device__ constexpr int twc_offset(int lb)
 }
 
 struct NttConsts {
-  Tw ninv;      // 1/N
-  Tw inv_last;  // (inverse twiddle of the last inverse stage) * 1/N
-  Tw twA[16];   // forward twiddles 0..R-1 (phase A, lane-uniform)
-  Tw itwA[16];  // inverse twiddles 0..R-1
+  Tw twA[16];  // forward twiddles 0..15 of the reference's table (phase A, lane-uniform)
+  Tw itwA[8];  // inverse twiddles 0..7 of the cyclic table: the stages on index bits 0..2 (phase C, lane-uniform)
 };
 
-enum { TW_UNIFORM = 0, TW_PHASE_B = 1, TW_PHASE_C = 2, TW_UNIFORM_LDS = 3 };
+enum { TW_UNIFORM = 0, TW_PHASE_B = 1, TW_PHASE_C = 2, TW_UNIFORM_LDS = 3, TW_PHASE_A = 4 };
 
 // element index held by (lane, reg m) in each phase
 template <int LOGN> __device__ __forceinline__ uint32_t idxA(uint32_t lane, int m) { return ((uint32_t)m << 6) | lane; }
@@ -105,13 +120,11 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Twiddle of the butterfly (m, m | 1<<lb) at global bit b. Reference index (ntt.hpp:133):
+// Forward twiddle of the butterfly (m, m | 1<<lb) at global bit b. Reference index (ntt.hpp:133):
 //   (N >> (b+1)) + (i >> (b+1)),  i >> (b+1) = (lanepart << (LB-1-lb)) | (m >> (lb+1)).
 // KIND selects where it lives; `tw` is the kernel-argument array, the phase-B LDS table, or this
 // lane's row of the phase-C LDS table. TW_UNIFORM_LDS: lane-uniform like TW_UNIFORM but read (as a broadcast)
-// from the LDS table that holds the reference-order twiddles -- Falcon-1024's widest phase-A stage has 8 twiddle
-// pairs per direction, which as kernel arguments pushed the kernel past its SGPR budget (the spills went to VGPR
-// lanes: 80 v_writelane / v_readlane per item).
+// from the LDS table that holds the reference-order twiddles.
 template <int LOGN, int KIND>
 __device__ __forceinline__ Tw twiddle(const Tw* __restrict__ tw, uint32_t lanepart, int b, int lb, int m)
 {
@@ -121,14 +134,25 @@ __device__ __forceinline__ Tw twiddle(const Tw* __restrict__ tw, uint32_t lanepa
   return tw[twc_offset<LOGN>(lb) + (m >> (lb + 1))];
 }
 
-// Instruction order inside a stage. Measured on the box (tools/valu_mix.hip, profiles/valu_mix_r01.json): a
-// full-rate instruction (add, sub) issues in 2 cycles only next to others of its kind; alternating with half-rate
-// instructions (the multiplies) it takes a 4-cycle slot like them. hipcc emits a stage butterfly after butterfly
-// (mul_hi, mul, mad, sub, add, mul_hi, ...), a dependent chain of five; grouped by kind (all mul_hi of the stage,
-// all mul, all mad, then all subs and adds) neighbours are independent and the adds form runs. In the kernels this
-// is worth 4 % for Falcon-1024 (8 butterflies per stage and lane, two waves per SIMD) and nothing measurable for
-// Falcon-512 (4 per stage, five waves per SIMD: the other waves already fill the slots). The fences keep hipcc's
-// scheduler from undoing the grouping: vector ALU instructions may not cross them, LDS, memory and scalar ones may.
+// Inverse (decimation-in-time) twiddle of the butterfly (m, m | 1<<lb) at global bit b: entry 2^b + (p mod 2^b) of
+// the cyclic table, p the element's index. The register part of p mod 2^b is m's bits below lb; the lane's part is
+// already in the pointer: phase C none (tw = kernel arguments), phase B tw = table + (lane & (2^PB - 1)) with the
+// register bits PB places up, phase A tw = table + lane with the register bits six places up.
+template <int LOGN, int KIND>
+__device__ __forceinline__ Tw itwiddle(const Tw* __restrict__ tw, int b, int lb, int m)
+{
+  const int jreg = m & ((1 << lb) - 1);
+  if constexpr (KIND == TW_UNIFORM) return tw[(1 << b) + jreg];
+  if constexpr (KIND == TW_PHASE_B) return tw[(1 << b) + (jreg << Geo<LOGN>::PB)];
+  return tw[(1 << b) + (jreg << 6)];
+}
+
+// Instruction order inside a stage. Measured on the box (tools/valu_mix.hip, tools/valu_r03.hip): hipcc emits a
+// stage butterfly after butterfly, a dependent chain; grouped by kind (all low products of the stage, all high
+// products, then all subs and adds) neighbours are independent. In the kernels this is worth 4 % for Falcon-1024
+// (8 butterflies per stage and lane, four waves per SIMD) and nothing measurable for Falcon-512 (4 per stage, five
+// waves per SIMD: the other waves already fill the slots). The fences keep hipcc's scheduler from undoing the
+// grouping: vector ALU instructions may not cross them, LDS, memory and scalar ones may.
 #ifndef FA_GROUPED
 #define FA_GROUPED 1
 #endif
@@ -139,36 +163,44 @@ __device__ __forceinline__ void valu_fence()
 #endif
 }
 
-// Cooley-Tukey stages on register bits LBTOP .. LBTOP-NST+1 of x[] (global bits BTOP ..).
-// Values are lazy signed residues (zq.hpp): a stage widens the bound by q, nothing is reduced.
-template <int LOGN, int NST, int BTOP, int LBTOP, int KIND>
-__device__ __forceinline__ void ct_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart)
+// Butterfly stages on register bits of x[]: t = w * x[hi] (Plantard, canonical), x[hi] = x[lo] - t, x[lo] += t.
+// FORWARD: bits LBTOP .. LBTOP-NST+1 (global bits BTOP ..), the reference's twiddles; else bits LBTOP .. LBTOP+NST-1
+// upwards (global bits BTOP ..), the cyclic twiddles of the inverse. FIRST: the transform's first stage, which adds
+// BIAS to the x[lo] of its butterflies (every later value descends from one of them); the inverse's first stage
+// (index bit 0) has the twiddle 1 throughout and multiplies nothing.
+template <int LOGN, bool FORWARD, int NST, int BTOP, int LBTOP, int KIND, bool FIRST>
+__device__ __forceinline__ void bfly_stages(uint32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart)
 {
   constexpr int R = Geo<LOGN>::R;
+  constexpr bool UNI = KIND == TW_UNIFORM;
 #pragma unroll
   for (int s = 0; s < NST; s++) {
-    const int b = BTOP - s, lb = LBTOP - s;
-    int32_t qh[R / 2], v[R / 2];
-    Tw t[R / 2];
+    const int b = FORWARD ? BTOP - s : BTOP + s, lb = FORWARD ? LBTOP - s : LBTOP + s;
+    const bool first = FIRST && s == 0;
+    const bool nomul = first && !FORWARD;
+    uint32_t v[R / 2];
     valu_fence();
 #pragma unroll
     for (int m = 0, k = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
-      t[k] = twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      qh[k] = mulhi_i32<KIND == TW_UNIFORM>(x[m | (1 << lb)], t[k].wp);
+      const uint32_t hi = x[m | (1 << lb)];
+      if (nomul)
+        v[k] = hi;
+      else
+        v[k] = plant_lo<UNI>(hi, FORWARD ? twiddle<LOGN, KIND>(tw, lanepart, b, lb, m) : itwiddle<LOGN, KIND>(tw, b, lb, m));
       k++;
     }
-    valu_fence();
+    if (!nomul) {
+      valu_fence();
 #pragma unroll
-    for (int m = 0, k = 0; m < R; m++) {
-      if (m & (1 << lb)) continue;
-      v[k] = __mul24(x[m | (1 << lb)], t[k].w);
-      k++;
+      for (int k = 0; k < R / 2; k++) v[k] = plant_hi(v[k]);
     }
     valu_fence();
+    if (first) {
 #pragma unroll
-    for (int k = 0; k < R / 2; k++) v[k] = msub_q(qh[k], v[k]);  // shoup(x, w, wp), in [0, q]
-    valu_fence();
+      for (int m = 0; m < R; m++)
+        if (!(m & (1 << lb))) x[m] += Geo<LOGN>::BIAS;
+    }
 #pragma unroll
     for (int m = 0, k = 0; m < R; m++) {
       if (m & (1 << lb)) continue;
@@ -185,90 +217,32 @@ __device__ __forceinline__ void ct_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* 
   }
 }
 
-// Gentleman-Sande stages on register bits LBBOT .. LBBOT+NST-1 (global bits BBOT ..), inverse
-// twiddles; same index rule. All values are >= 0 here (sums of values in [0, q]); the sums double
-// per stage, so with REDUCE the sum outputs of the last stage are brought back to [0, q].
-// LAST: the final stage of the transform also multiplies by 1/N (ntt.hpp:193-199 folded in).
-template <int LOGN, int NST, int BBOT, int LBBOT, bool LAST, bool REDUCE, int KIND>
-__device__ __forceinline__ void gs_stages(int32_t (&x)[Geo<LOGN>::R], const Tw* __restrict__ tw, uint32_t lanepart,
-                                          const NttConsts& nc)
-{
-  constexpr int R = Geo<LOGN>::R;
-#pragma unroll
-  for (int s = 0; s < NST; s++) {
-    const int b = BBOT + s, lb = LBBOT + s;
-    const bool last = LAST && s == NST - 1;
-    const bool red = !last && REDUCE && s == NST - 1;
-    int32_t d[R / 2], qh[R / 2], qu[R / 2];
-    Tw t[R / 2];
-    valu_fence();
-#pragma unroll
-    for (int m = 0, k = 0; m < R; m++) {  // differences and sums first: a run of full-rate instructions
-      if (m & (1 << lb)) continue;
-      d[k] = x[m] - x[m | (1 << lb)];
-      k++;
-    }
-#pragma unroll
-    for (int m = 0; m < R; m++) {
-      if (m & (1 << lb)) continue;
-      x[m] = x[m] + x[m | (1 << lb)];
-    }
-    valu_fence();
-#pragma unroll
-    for (int m = 0, k = 0; m < R; m++) {
-      if (m & (1 << lb)) continue;
-      t[k] = last ? nc.inv_last : twiddle<LOGN, KIND>(tw, lanepart, b, lb, m);
-      qh[k] = mulhi_i32<LAST || KIND == TW_UNIFORM>(d[k], t[k].wp);
-      if (last) qu[k] = mulhi_i32<true>(x[m], nc.ninv.wp);
-      if (red) qu[k] = mulhi_i32<true>(x[m], RQ32);
-      k++;
-    }
-    valu_fence();
-#pragma unroll
-    for (int m = 0, k = 0; m < R; m++) {
-      if (m & (1 << lb)) continue;
-      d[k] = __mul24(d[k], t[k].w);
-      if (last) x[m] = __mul24(x[m], nc.ninv.w);
-      k++;
-    }
-    valu_fence();
-#pragma unroll
-    for (int m = 0, k = 0; m < R; m++) {
-      if (m & (1 << lb)) continue;
-      x[m | (1 << lb)] = msub_q(qh[k], d[k]);       // shoup(d, w, wp)
-      if (last || red) x[m] = msub_q(qu[k], x[m]);  // shoup(u, 1/N) resp. reduce(u)
-      k++;
-    }
-    valu_fence();
-  }
-}
-
 template <int LOGN, int PHASE_FROM>  // 0: A->B, 1: B->C, 2: C->B, 3: B->A
-__device__ __forceinline__ void transpose_out(const int32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
+__device__ __forceinline__ void transpose_out(const uint32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
 {
   constexpr int R = Geo<LOGN>::R;
 #pragma unroll
   for (int m = 0; m < R; m++) {
-    if constexpr (PHASE_FROM == 0) buf[padAB<LOGN>(idxA<LOGN>(lane, m))] = (uint32_t)x[m];
-    if constexpr (PHASE_FROM == 1) buf[padBC<LOGN>(idxB<LOGN>(lane, m))] = (uint32_t)x[m];
-    if constexpr (PHASE_FROM == 2) buf[padBC<LOGN>(idxC<LOGN>(lane, m))] = (uint32_t)x[m];
-    if constexpr (PHASE_FROM == 3) buf[padAB<LOGN>(idxB<LOGN>(lane, m))] = (uint32_t)x[m];
+    if constexpr (PHASE_FROM == 0) buf[padAB<LOGN>(idxA<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 1) buf[padBC<LOGN>(idxB<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 2) buf[padBC<LOGN>(idxC<LOGN>(lane, m))] = x[m];
+    if constexpr (PHASE_FROM == 3) buf[padAB<LOGN>(idxB<LOGN>(lane, m))] = x[m];
   }
 }
 template <int LOGN, int PHASE_FROM>
-__device__ __forceinline__ void transpose_in(int32_t (&x)[Geo<LOGN>::R], const uint32_t* __restrict__ buf, uint32_t lane)
+__device__ __forceinline__ void transpose_in(uint32_t (&x)[Geo<LOGN>::R], const uint32_t* __restrict__ buf, uint32_t lane)
 {
   constexpr int R = Geo<LOGN>::R;
 #pragma unroll
   for (int m = 0; m < R; m++) {
-    if constexpr (PHASE_FROM == 0) x[m] = (int32_t)buf[padAB<LOGN>(idxB<LOGN>(lane, m))];
-    if constexpr (PHASE_FROM == 1) x[m] = (int32_t)buf[padBC<LOGN>(idxC<LOGN>(lane, m))];
-    if constexpr (PHASE_FROM == 2) x[m] = (int32_t)buf[padBC<LOGN>(idxB<LOGN>(lane, m))];
-    if constexpr (PHASE_FROM == 3) x[m] = (int32_t)buf[padAB<LOGN>(idxA<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 0) x[m] = buf[padAB<LOGN>(idxB<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 1) x[m] = buf[padBC<LOGN>(idxC<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 2) x[m] = buf[padBC<LOGN>(idxB<LOGN>(lane, m))];
+    if constexpr (PHASE_FROM == 3) x[m] = buf[padAB<LOGN>(idxA<LOGN>(lane, m))];
   }
 }
 template <int LOGN, int PHASE_FROM>
-__device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
+__device__ __forceinline__ void transpose(uint32_t (&x)[Geo<LOGN>::R], uint32_t* __restrict__ buf, uint32_t lane)
 {
   transpose_out<LOGN, PHASE_FROM>(x, buf, lane);
   wave_lds_sync();
@@ -279,44 +253,47 @@ __device__ __forceinline__ void transpose(int32_t (&x)[Geo<LOGN>::R], uint32_t* 
 // Per-wave view of the twiddle tables.
 struct TwTabs {
   const Tw* fA;  // kernel arguments
-  const Tw* iA;
   const Tw* fB;  // LDS, phase B
-  const Tw* iB;
   const Tw* fC;  // LDS, this lane's phase-C row
-  const Tw* iC;
+  const Tw* iC;  // kernel arguments
+  const Tw* iB;  // LDS, the cyclic table + (lane & (2^PB - 1))
+  const Tw* iA;  // LDS, the cyclic table + lane
+  const Tw* sc;  // LDS, the final scaling zeta^-p / N, + lane
 };
 
 // Phase A of the forward transform: the stages on the register-held index bits [6, logn), lane-uniform twiddles.
+// Falcon-1024's widest stage (8 twiddles) reads them from LDS as a broadcast: as kernel arguments they pushed the
+// kernel past its SGPR budget (the spills went to VGPR lanes).
 template <int LOGN>
-__device__ __forceinline__ void phase_a_forward(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T)
+__device__ __forceinline__ void phase_a_forward(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T)
 {
   using G = Geo<LOGN>;
   if constexpr (LOGN == 10) {
-    ct_stages<LOGN, G::LB - 1, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
-    ct_stages<LOGN, 1, 6, 0, TW_UNIFORM_LDS>(x, T.fB, 0u);
+    bfly_stages<LOGN, true, G::LB - 1, LOGN - 1, G::LB - 1, TW_UNIFORM, true>(x, T.fA, 0u);
+    bfly_stages<LOGN, true, 1, 6, 0, TW_UNIFORM_LDS, false>(x, T.fB, 0u);
   } else {
-    ct_stages<LOGN, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM>(x, T.fA, 0u);
+    bfly_stages<LOGN, true, G::LB, LOGN - 1, G::LB - 1, TW_UNIFORM, true>(x, T.fA, 0u);
   }
 }
 
-// x: |x| < 2^16 in phase-A layout  ->  NTT in phase-C layout, |x| < 2^16 + logn*q
+// x: < 2^16, phase-A layout (natural order)  ->  NTT in phase-C layout (bit-reversed order), < 2^16 + 2 logn q
 template <int LOGN>
-__device__ __forceinline__ void ntt_forward(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
+__device__ __forceinline__ void ntt_forward(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
                                             uint32_t lane)
 {
   using G = Geo<LOGN>;
   phase_a_forward<LOGN>(x, T);
   transpose<LOGN, 0>(x, buf, lane);
-  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB);
+  bfly_stages<LOGN, true, G::LB, 5, G::LB - 1, TW_PHASE_B, false>(x, T.fB, lane >> G::PB);
   transpose<LOGN, 1>(x, buf, lane);
-  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane);
+  bfly_stages<LOGN, true, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C, false>(x, T.fC, lane);
 }
 
-// Two independent forward transforms side by side (the s2 and h of one item, or a and b of one product):
+// Two independent forward transforms side by side (a and b of one product, f and g of one key):
 // stage for stage on both, each with its own transpose buffer, so one transform's LDS round trips and
-// dependent Shoup chains hide behind the other's arithmetic.
+// dependent product chains hide behind the other's arithmetic.
 template <int LOGN>
-__device__ __forceinline__ void ntt_forward2(int32_t (&x)[Geo<LOGN>::R], int32_t (&y)[Geo<LOGN>::R], const TwTabs& T,
+__device__ __forceinline__ void ntt_forward2(uint32_t (&x)[Geo<LOGN>::R], uint32_t (&y)[Geo<LOGN>::R], const TwTabs& T,
                                              uint32_t* __restrict__ bufx, uint32_t* __restrict__ bufy, uint32_t lane)
 {
   using G = Geo<LOGN>;
@@ -328,64 +305,67 @@ __device__ __forceinline__ void ntt_forward2(int32_t (&x)[Geo<LOGN>::R], int32_t
   transpose_in<LOGN, 0>(x, bufx, lane);
   transpose_in<LOGN, 0>(y, bufy, lane);
   wave_lds_sync();
-  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(x, T.fB, lane >> G::PB);
+  bfly_stages<LOGN, true, G::LB, 5, G::LB - 1, TW_PHASE_B, false>(x, T.fB, lane >> G::PB);
   transpose_out<LOGN, 1>(x, bufx, lane);
-  ct_stages<LOGN, G::LB, 5, G::LB - 1, TW_PHASE_B>(y, T.fB, lane >> G::PB);
+  bfly_stages<LOGN, true, G::LB, 5, G::LB - 1, TW_PHASE_B, false>(y, T.fB, lane >> G::PB);
   transpose_out<LOGN, 1>(y, bufy, lane);
   wave_lds_sync();
   transpose_in<LOGN, 1>(x, bufx, lane);
   transpose_in<LOGN, 1>(y, bufy, lane);
   wave_lds_sync();
-  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(x, T.fC, lane);
-  ct_stages<LOGN, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C>(y, T.fC, lane);
+  bfly_stages<LOGN, true, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C, false>(x, T.fC, lane);
+  bfly_stages<LOGN, true, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C, false>(y, T.fC, lane);
 }
 
-// x: in (-q/60, q + q/60) (mulmod_lazy), phase-C layout (bit-reversed order) -> coefficients in phase-A
-// layout, each in [0, q], already multiplied by 1/N. Phases C and B are six stages together (bound 64q < 2^19 on
-// the differences fed to shoup), so one reduction of the sums after phase B is enough.
+// x: <= q, phase-C layout (bit-reversed order)  ->  coefficients in phase-A layout (natural order), canonical,
+// the 1/N of ntt.hpp:193-199 included in the final scaling.
 template <int LOGN>
-__device__ __forceinline__ void ntt_inverse(int32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
-                                            uint32_t lane, const NttConsts& nc)
+__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
+                                            uint32_t lane)
 {
   using G = Geo<LOGN>;
-  static_assert(G::PB + G::LB == 6, "phases C and B together are six stages");
-  gs_stages<LOGN, G::PB, 0, 0, false, false, TW_PHASE_C>(x, T.iC, lane, nc);
+  constexpr int R = G::R;
+  static_assert(G::PB <= 3, "the lane-uniform inverse twiddles are entries 1..7 of the cyclic table");
+  bfly_stages<LOGN, false, G::PB, 0, 0, TW_UNIFORM, true>(x, T.iC, 0u);
   transpose<LOGN, 2>(x, buf, lane);
-  gs_stages<LOGN, G::LB, G::PB, 0, false, true, TW_PHASE_B>(x, T.iB, lane >> G::PB, nc);
+  bfly_stages<LOGN, false, G::LB, G::PB, 0, TW_PHASE_B, false>(x, T.iB, 0u);
   transpose<LOGN, 3>(x, buf, lane);
-  if constexpr (LOGN == 10) {
-    gs_stages<LOGN, 1, 6, 0, false, false, TW_UNIFORM_LDS>(x, T.iB, 0u, nc);
-    gs_stages<LOGN, G::LB - 1, 7, 1, true, false, TW_UNIFORM>(x, T.iA, 0u, nc);
-  } else {
-    gs_stages<LOGN, G::LB, 6, 0, true, false, TW_UNIFORM>(x, T.iA, 0u, nc);
-  }
+  bfly_stages<LOGN, false, G::LB, 6, 0, TW_PHASE_A, false>(x, T.iA, 0u);
+  valu_fence();
+#pragma unroll
+  for (int m = 0; m < R; m++) x[m] = plant_lo<false>(x[m], T.sc[m << 6]);
+  valu_fence();
+#pragma unroll
+  for (int m = 0; m < R; m++) x[m] = plant_hi(x[m]);
+  valu_fence();
 }
 
 // Workgroup-shared twiddle tables in LDS and their one-time fill.
 template <int LOGN>
 struct TwLds {
-  Tw fB[Geo<LOGN>::TWB], iB[Geo<LOGN>::TWB];
-  Tw fC[64 * Geo<LOGN>::TWC], iC[64 * Geo<LOGN>::TWC];
+  Tw fB[Geo<LOGN>::TWB];      // forward, reference order, entries below N >> PB
+  Tw fC[64 * Geo<LOGN>::TWC]; // forward, per lane
+  Tw inv[Geo<LOGN>::N];       // inverse: entry 2^b + j = omega^-(N/2^(b+1) * j), j < 2^b
+  Tw sc[Geo<LOGN>::N];        // inverse: entry p = zeta^-p / N
 };
 template <int LOGN>
 __device__ __forceinline__ void fill_tw_lds(TwLds<LOGN>& L, const Tw* __restrict__ tw, const Tw* __restrict__ itw,
-                                            const Tw* __restrict__ twc, const Tw* __restrict__ itwc)
+                                            const Tw* __restrict__ twc, const Tw* __restrict__ isc)
 {
   using G = Geo<LOGN>;
-  for (int i = threadIdx.x; i < G::TWB; i += blockDim.x) {
-    L.fB[i] = tw[i];
-    L.iB[i] = itw[i];
-  }
-  for (int i = threadIdx.x; i < 64 * G::TWC; i += blockDim.x) {
-    L.fC[i] = twc[i];
-    L.iC[i] = itwc[i];
+  for (int i = threadIdx.x; i < G::TWB; i += blockDim.x) L.fB[i] = tw[i];
+  for (int i = threadIdx.x; i < 64 * G::TWC; i += blockDim.x) L.fC[i] = twc[i];
+  for (int i = threadIdx.x; i < G::N; i += blockDim.x) {
+    L.inv[i] = itw[i];
+    L.sc[i] = isc[i];
   }
   __syncthreads();
 }
 template <int LOGN>
 __device__ __forceinline__ TwTabs make_tabs(const TwLds<LOGN>& L, const NttConsts& nc, uint32_t lane)
 {
-  return TwTabs{ nc.twA, nc.itwA, L.fB, L.iB, L.fC + lane * Geo<LOGN>::TWC, L.iC + lane * Geo<LOGN>::TWC };
+  using G = Geo<LOGN>;
+  return TwTabs{ nc.twA, L.fB, L.fC + lane * G::TWC, nc.itwA, L.inv + (lane & ((1u << G::PB) - 1u)), L.inv + lane, L.sc + lane };
 }
 
 struct DebugOut {  // device pointers, any may be null
@@ -407,10 +387,10 @@ struct VerifyArgs {
   const uint32_t* sqn;      // [slots]
   const uint8_t* st2;       // [slots]
   const uint32_t* idx;      // slot -> item, nullable
-  const Tw* tw;             // forward twiddles [N], reference order
-  const Tw* itw;            // inverse twiddles [N]
-  const Tw* twc;            // phase-C tables [64][TWC]
-  const Tw* itwc;
+  const Tw* tw;             // forward twiddles [N], reference order (ntt.hpp:62-83), Plantard form
+  const Tw* itw;            // inverse twiddles [N], the cyclic table (TwLds::inv)
+  const Tw* twc;            // forward phase-C table [64][TWC]
+  const Tw* isc;            // inverse scaling [N] (TwLds::sc)
   NttConsts nc;
   uint32_t count;           // slots
   const uint32_t* dcount;   // nullable: device-side number of slots, count = min(count, *dcount) (retry pass, mixed batches)
@@ -431,7 +411,7 @@ constexpr uint32_t PREPARED_BAD_KEY = 0xffffu;  // first coefficient of a prepar
 // (phase-A layout, raw values <= 16383).
 template <int LOGN>
 __device__ __forceinline__ void unpack_pkey(const uint32_t (&pkw)[Geo<LOGN>::PKDW], uint32_t pal, uint32_t* __restrict__ pkb,
-                                            uint32_t lane, int32_t (&y)[Geo<LOGN>::R])
+                                            uint32_t lane, uint32_t (&y)[Geo<LOGN>::R])
 {
   using G = Geo<LOGN>;
 #pragma unroll
@@ -445,11 +425,12 @@ __device__ __forceinline__ void unpack_pkey(const uint32_t (&pkw)[Geo<LOGN>::PKD
   static_assert(14 * 64 == 28 * 32 && ((3 + 1) * 8 + 14 * (Geo<LOGN>::N - 1)) / 32 + 1 < Geo<LOGN>::PKDW * 64, "pk row layout");
 #pragma unroll
   for (int m = 0; m < G::R; m++)
-    y[m] = (int32_t)(__builtin_amdgcn_alignbit(src[28 * m + 1], src[28 * m], sh) & 0x3fffu);  // <= 16383, reduced by the transform itself
+    y[m] = __builtin_amdgcn_alignbit(src[28 * m + 1], src[28 * m], sh) & 0x3fffu;  // <= 16383, reduced by the transform itself
 }
 
-// Prepared keys: NTT(h) of a public key, canonical u16, in the order the verify kernel consumes it
-// (lane L holds positions L*R .. L*R+R-1 of the transform's bit-reversed output). One wave per key.
+// Prepared keys: NTT(h) of a public key times -2^32 (the factor the verify kernel's two-variable Plantard product
+// divides by, zq.hpp plant2), canonical u16, in the order the verify kernel consumes it (lane L holds positions
+// L*R .. L*R+R-1 of the transform's bit-reversed output): an opaque blob. One wave per key.
 // PACKED: input rows are encoded keys (decode_pkey, decoding.hpp:18-48; a wrong header yields the
 // PREPARED_BAD_KEY mark, the counterpart of falcon.hpp:240-243); else rows are decoded polynomials h as
 // verification::verify takes them (N u16, any value: the ff_t arithmetic reduces, ff.hpp:69-76).
@@ -457,7 +438,7 @@ template <int LOGN, bool PACKED>
 __global__ __launch_bounds__(VERIFY_WG) void prepare_keys_kernel(const uint8_t* __restrict__ pk, const uint16_t* __restrict__ h,
                                                                  uint32_t nkeys, uint16_t* __restrict__ prepared,
                                                                  const Tw* __restrict__ tw, const Tw* __restrict__ itw,
-                                                                 const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                                 const Tw* __restrict__ twc, const Tw* __restrict__ isc,
                                                                  const NttConsts nc)
 {
   using G = Geo<LOGN>;
@@ -465,11 +446,11 @@ __global__ __launch_bounds__(VERIFY_WG) void prepare_keys_kernel(const uint8_t* 
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
-  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < nkeys; key += gridDim.x * VERIFY_WAVES) {
-    int32_t y[R];
+    uint32_t y[R];
     bool ok = true;
     if constexpr (PACKED) {
       const uint8_t* pkrow = pk + (size_t)key * G::PKLEN;
@@ -483,13 +464,13 @@ __global__ __launch_bounds__(VERIFY_WG) void prepare_keys_kernel(const uint8_t* 
       unpack_pkey<LOGN>(pkw, pal, s_pk[wave], lane, y);
     } else {
 #pragma unroll
-      for (int m = 0; m < R; m++) y[m] = (int32_t)h[(size_t)key * N + idxA<LOGN>(lane, m)];
+      for (int m = 0; m < R; m++) y[m] = h[(size_t)key * N + idxA<LOGN>(lane, m)];
     }
     ntt_forward<LOGN>(y, T, s_buf[wave], lane);
     uint32_t* out = (uint32_t*)(prepared + (size_t)key * N) + lane * (R / 2);
 #pragma unroll
     for (int j = 0; j < R / 2; j++) {
-      uint32_t lo = csub((uint32_t)reduce(y[2 * j]), Q), hi = csub((uint32_t)reduce(y[2 * j + 1]), Q);
+      uint32_t lo = plant(y[2 * j], W_NEG_R), hi = plant(y[2 * j + 1], W_NEG_R);
       if (!ok) lo = hi = 0u;
       if (!ok && j == 0 && lane == 0) lo = PREPARED_BAD_KEY;
       out[j] = lo | (hi << 16);
@@ -655,11 +636,11 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
     // ---- what the transforms need, out of the loaded words: s2 (already lifted to [0,q), verification.hpp:36-39) and
     //      the key ----
     const bool run = status == ST_OK && !done;
-    int32_t x[R], y[R];
+    uint32_t x[R], y[R];
     uint32_t hk[PREPARED ? R / 2 : 1], s2keep[DEBUG ? R : 1];
     if (run) {
 #pragma unroll
-      for (int m = 0; m < R; m++) x[m] = (int32_t)cur.s2v[m];
+      for (int m = 0; m < R; m++) x[m] = cur.s2v[m];
       if constexpr (DEBUG) {
 #pragma unroll
         for (int m = 0; m < R; m++) s2keep[m] = cur.s2v[m];
@@ -700,9 +681,9 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       if constexpr (PREPARED) {
         ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
-        for (int m = 0; m < R; m++) {  // NTT(h), canonical, already in this lane's phase-C positions
+        for (int m = 0; m < R; m++) {  // -2^32 NTT(h), canonical, already in this lane's phase-C positions
           const uint32_t hv = (hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
-          x[m] = mulmod_lazy(x[m], (int32_t)hv);  // polynomial.hpp:99-110; |x| <= 11q, hv < q
+          x[m] = plant2(x[m], hv);  // polynomial.hpp:99-110; x < 2^16 + 2 logn q, hv < q: the product is below 2^32
         }
       } else {
         // One transform after the other: interleaving them (ntt_forward2) costs Falcon-1024 its third wave per SIMD
@@ -710,9 +691,11 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         ntt_forward<LOGN>(y, T, buf, lane);
         ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
-        for (int m = 0; m < R; m++) x[m] = mulmod_lazy(reduce(x[m]), y[m]);  // polynomial.hpp:99-110; |y| <= 16383 + 10q
+        for (int m = 0; m < R; m++) x[m] = plant(x[m], W_NEG_R);  // canonical, times -2^32
+#pragma unroll
+        for (int m = 0; m < R; m++) x[m] = plant2(x[m], y[m]);    // polynomial.hpp:99-110; y < 16384 + 2 logn q
       }
-      ntt_inverse<LOGN>(x, T, buf, lane, A.nc);  // x = s2*h, natural order, phase-A layout
+      ntt_inverse<LOGN>(x, T, buf, lane);  // x = s2*h, natural order, phase-A layout, canonical
 
       // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
       uint32_t acc = 0;
@@ -720,7 +703,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       for (int m = 0; m < R; m++) {
         const uint32_t i = idxA<LOGN>(lane, m);
         const uint32_t craw = cbuf[i];                              // < 61445
-        const uint32_t r0 = (uint32_t)reduce((int32_t)craw - x[m]); // s1 in [0, q] (x[m] in [0, q])
+        const uint32_t r0 = (uint32_t)reduce((int32_t)craw - (int32_t)x[m]); // s1 in [0, q] (x[m] in [0, q))
         const uint32_t mag = r0 >= A.half ? Q - r0 : r0;            // |centred s1|, verification.hpp:59-68 (q -> 0)
         acc += mul24(mag, mag);
         const uint32_t r = DEBUG ? csub(r0, Q) : r0;                // canonical s1, debug output only
@@ -762,7 +745,7 @@ __global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VW][G::XBUF];  // transposes
   __shared__ uint16_t s_c[VW][G::N];
-  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.itwc);
+  fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.isc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
   const uint32_t count = GENERAL && A.dcount ? min(A.count, *A.dcount) : A.count;
@@ -820,7 +803,7 @@ template <int LOGN>
 __global__ __launch_bounds__(VERIFY_WG) void pubkey_kernel(const int32_t* __restrict__ f, const int32_t* __restrict__ g,
                                                            uint16_t* __restrict__ h, uint32_t count,
                                                            const Tw* __restrict__ tw, const Tw* __restrict__ itw,
-                                                           const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                           const Tw* __restrict__ twc, const Tw* __restrict__ isc,
                                                            const NttConsts nc)
 {
   using G = Geo<LOGN>;
@@ -828,32 +811,32 @@ __global__ __launch_bounds__(VERIFY_WG) void pubkey_kernel(const int32_t* __rest
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
-  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < count; key += gridDim.x * VERIFY_WAVES) {
-    int32_t x[R], y[R];
+    uint32_t x[R], y[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
       const int32_t fv = f[(size_t)key * N + idxA<LOGN>(lane, m)], gv = g[(size_t)key * N + idxA<LOGN>(lane, m)];
-      x[m] = fv < 0 ? fv + QI : fv;
-      y[m] = gv < 0 ? gv + QI : gv;
+      x[m] = (uint32_t)reduce(fv);  // [0, q], keygen.hpp:80-83 (any |v| < 2^22 is taken mod q)
+      y[m] = (uint32_t)reduce(gv);
     }
     ntt_forward2<LOGN>(x, y, T, s_buf[wave], s_buf2[wave], lane);
 #pragma unroll
     for (int m = 0; m < R; m++) {
-      const int32_t b = (int32_t)csub((uint32_t)reduce(x[m]), Q);  // canonical NTT(f) element
+      const int32_t b = (int32_t)plant(x[m], W_ONE);  // canonical NTT(f) element
       int32_t inv = b;                                            // b^(q-2), q - 2 = 0b10111111111111
 #pragma unroll
       for (int bit = 12; bit >= 0; bit--) {
         inv = mulmod(inv, inv);
         if ((12287 >> bit) & 1) inv = mulmod(inv, b);
       }
-      x[m] = mulmod(reduce(y[m]), inv);
+      x[m] = (uint32_t)mulmod((int32_t)plant(y[m], W_ONE), inv);
     }
-    ntt_inverse<LOGN>(x, T, s_buf[wave], lane, nc);
+    ntt_inverse<LOGN>(x, T, s_buf[wave], lane);
 #pragma unroll
-    for (int m = 0; m < R; m++) h[(size_t)key * N + idxA<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)x[m], Q);
+    for (int m = 0; m < R; m++) h[(size_t)key * N + idxA<LOGN>(lane, m)] = (uint16_t)x[m];
   }
 }
 
@@ -866,30 +849,30 @@ __global__ __launch_bounds__(VERIFY_WG) void pubkey_kernel(const int32_t* __rest
 template <int LOGN, bool INVERSE>
 __global__ __launch_bounds__(VERIFY_WG) void ntt_kernel(const uint16_t* __restrict__ a, uint16_t* __restrict__ out, uint32_t count,
                                                         const Tw* __restrict__ tw, const Tw* __restrict__ itw,
-                                                        const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                        const Tw* __restrict__ twc, const Tw* __restrict__ isc,
                                                         const NttConsts nc)
 {
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
-  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   for (uint32_t p = blockIdx.x * VERIFY_WAVES + wave; p < count; p += gridDim.x * VERIFY_WAVES) {
-    int32_t x[R];
+    uint32_t x[R];
     if constexpr (!INVERSE) {
 #pragma unroll
-      for (int m = 0; m < R; m++) x[m] = (int32_t)a[(size_t)p * N + idxA<LOGN>(lane, m)];
+      for (int m = 0; m < R; m++) x[m] = a[(size_t)p * N + idxA<LOGN>(lane, m)];
       ntt_forward<LOGN>(x, T, s_buf[wave], lane);
 #pragma unroll
-      for (int m = 0; m < R; m++) out[(size_t)p * N + idxC<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)reduce(x[m]), Q);
+      for (int m = 0; m < R; m++) out[(size_t)p * N + idxC<LOGN>(lane, m)] = (uint16_t)plant(x[m], W_ONE);
     } else {
 #pragma unroll
-      for (int m = 0; m < R; m++) x[m] = reduce((int32_t)a[(size_t)p * N + idxC<LOGN>(lane, m)]);
-      ntt_inverse<LOGN>(x, T, s_buf[wave], lane, nc);
+      for (int m = 0; m < R; m++) x[m] = plant(a[(size_t)p * N + idxC<LOGN>(lane, m)], W_ONE);
+      ntt_inverse<LOGN>(x, T, s_buf[wave], lane);
 #pragma unroll
-      for (int m = 0; m < R; m++) out[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)x[m], Q);
+      for (int m = 0; m < R; m++) out[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)x[m];
     }
     wave_lds_sync();
   }
@@ -916,7 +899,7 @@ __global__ __launch_bounds__(VERIFY_WG) void decode_pkeys_kernel(const uint8_t* 
 #pragma unroll
     for (int t = 0; t < G::PKDW; t++) pkw[t] = pbase[min(t * 64u + lane, last_dw)];
     const bool good = ((__builtin_amdgcn_readfirstlane(pkw[0]) >> (8u * __builtin_amdgcn_readfirstlane(pal))) & 0xffu) == (uint32_t)LOGN;
-    int32_t y[R];
+    uint32_t y[R];
     unpack_pkey<LOGN>(pkw, pal, s_pk[wave], lane, y);
 #pragma unroll
     for (int m = 0; m < R; m++) h[(size_t)key * N + idxA<LOGN>(lane, m)] = good ? (uint16_t)y[m] : (uint16_t)0;
@@ -965,7 +948,7 @@ template <int LOGN>
 __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                             uint16_t* __restrict__ c, uint32_t count,
                                                             const Tw* __restrict__ tw, const Tw* __restrict__ itw,
-                                                            const Tw* __restrict__ twc, const Tw* __restrict__ itwc,
+                                                            const Tw* __restrict__ twc, const Tw* __restrict__ isc,
                                                             const NttConsts nc)
 {
   using G = Geo<LOGN>;
@@ -973,7 +956,7 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
-  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, itwc);
+  fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t* buf = s_buf[wave];
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
@@ -998,18 +981,20 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
         bn[m] = b[(size_t)np * N + idxA<LOGN>(lane, m)];
       }
     }
-    int32_t x[R], y[R];
+    uint32_t x[R], y[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
-      x[m] = (int32_t)av[m];  // inputs may be any u16 (the reference's ff_t ctor reduces, ff.hpp:69-76): lazy residues
-      y[m] = (int32_t)bv[m];
+      x[m] = av[m];  // inputs may be any u16 (the reference's ff_t ctor reduces, ff.hpp:69-76): lazy residues
+      y[m] = bv[m];
     }
     ntt_forward2<LOGN>(x, y, T, buf, s_buf2[wave], lane);
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = mulmod(reduce(x[m]), reduce(y[m]));
-    ntt_inverse<LOGN>(x, T, buf, lane, nc);
+    for (int m = 0; m < R; m++) x[m] = plant(x[m], W_NEG_R);  // canonical, times -2^32
 #pragma unroll
-    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)csub((uint32_t)x[m], Q);
+    for (int m = 0; m < R; m++) x[m] = plant2(x[m], y[m]);    // polynomial.hpp:99-110; y < 2^16 + 2 logn q
+    ntt_inverse<LOGN>(x, T, buf, lane);
+#pragma unroll
+    for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)x[m];
     if (!more) break;
 #pragma unroll
     for (int m = 0; m < R; m++) {

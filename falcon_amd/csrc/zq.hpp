@@ -1,21 +1,23 @@
 // zq.hpp -- Z_q (q = 12289) arithmetic for gfx950 VALU.
 //
 // Replaces the reference's Barrett ff_t (ff.hpp:64-167). Any exact reduction yields the same
-// canonical residues, so parity is unaffected; the form below is chosen
-// for the CDNA4 vector ALU, where every integer multiply (24- or 32-bit, low or high half) issues
-// at the same half rate and adds/subtracts at full rate (profiles/valu_peak_r01.json):
-//   * values live in VGPRs as signed 32-bit integers that are only congruent to the residue
-//     ("lazy"), with |x| < 2^19 wherever x feeds a multiplication;
-//   * a twiddle w is stored centred, w in (-q/2, q/2), with its Shoup companion
-//     wp = round(w * 2^32 / q); then
-//       shoup(x, w, wp) = x*w - floor(x*wp / 2^32) * q   is in [0, q]   for |x| < 2^19
-//     and costs exactly three VALU instructions (v_mul_hi_i32, v_mul_i32_i24, v_mad_i32_i24);
-//   * a butterfly is shoup + one add + one subtract: sums and differences are never reduced in
-//     the forward transform (the bound grows by q per stage, 11q after ten stages), and once in
-//     the inverse transform (where sums double per stage).
-// Why [0, q]: x*wp/2^32 = x*w/q + d with |d| < 2^19 * 0.5 / 2^32 = 2^-14 < 1/q, and the fractional
-// part of x*w/q is a multiple of 1/q, so the floor is exact except when x*w/q is an integer and
-// d < 0, which yields q instead of 0.
+// canonical residues, so parity is unaffected; the forms below are chosen
+// for the CDNA4 vector ALU. Measured on the box (tools/valu_r03.hip, profiles/valu_peak_r03.json): in a
+// butterfly-shaped stream every vector instruction -- 24- or 32-bit multiply, low or high half, mad, add, sub --
+// costs one issue slot of about four cycles, so the only lever is the NUMBER of instructions.
+//
+// Round 3: the transforms multiply by constants in Plantard's form (T. Plantard, "Efficient word size modular
+// arithmetic", 2021), two instructions instead of the three of the Shoup product used until then:
+//     W  = ((-w * 2^32) mod q) * q^-1 mod 2^32          (host side, one dword per twiddle)
+//     plant(a, W) = floor(((a * W) mod 2^32) * q / 2^32) = (a * w) mod q,  CANONICAL, for 0 <= a < 2^32 / q
+//   (v_mul_lo_u32, v_mul_hi_u32). Why: X = a*W mod 2^32 satisfies X*q = a*wt + k*2^32 with wt = (-w*2^32) mod q,
+//   so k = (X*q - a*wt) / 2^32 is the integer floor(X*q / 2^32) as long as 0 <= a*wt < 2^32, and
+//   k*2^32 = -a*wt = a*w*2^32 (mod q) gives k = a*w (mod q) with 0 <= k < q.
+//   Values therefore live in VGPRs as UNSIGNED lazy residues below 2^32/q = 349,496 (28 q); a Cooley-Tukey
+//   butterfly is plant + add + sub = 4 instructions, its difference kept non-negative by a multiple of q added
+//   once per transform (verify_kernel.hpp). The same identity with two variable factors (a*b < 2^32) is
+//   plant2(a, b) = -(a*b) * 2^-32 mod q; the stray factor is folded into a constant elsewhere.
+// The signed Barrett forms further down (reduce, mulmod, mulmod_lazy) remain for the places outside the transforms.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,12 +26,45 @@ namespace fa {
 
 constexpr uint32_t Q = 12289u;
 constexpr int32_t QI = 12289;
-constexpr int32_t RQ32 = 349496;  // round(2^32 / q): Shoup companion of w = 1
+constexpr int32_t RQ32 = 349496;  // round(2^32 / q): the signed Barrett multiplier of reduce()
 
-struct alignas(8) Tw {  // 8-byte aligned: one ds_read_b64 (banked mod 64) instead of a ds_read2_b32 (banked mod 32, 2-way conflicts on the per-lane tables)
-  int32_t w;   // twiddle, centred in (-q/2, q/2)
-  int32_t wp;  // round(w * 2^32 / q)
-};
+typedef uint32_t Tw;  // a twiddle in Plantard's form, plant_const(w)
+
+constexpr uint32_t QINV32 = 150982657u;              // q^-1 mod 2^32
+static_assert((uint32_t)(QINV32 * Q) == 1u, "q^-1 mod 2^32");
+constexpr uint32_t PLANT_LIMIT = 349496u;            // floor(2^32 / q): plant() takes 0 <= a < PLANT_LIMIT
+// W for the constant w (any residue): hi32((a * W mod 2^32) * q) = a * w mod q.
+__host__ __device__ constexpr uint32_t plant_const(uint32_t w)
+{
+  const uint64_t wt = (Q - (uint64_t)(w % Q) * ((1ull << 32) % Q) % Q) % Q;  // (-w * 2^32) mod q
+  return (uint32_t)(wt * QINV32);
+}
+constexpr uint32_t W_ONE = plant_const(1u);                               // plant(a, W_ONE) = a mod q
+constexpr uint32_t NEG_R = (Q - (uint32_t)((1ull << 32) % Q)) % Q;        // -2^32 mod q
+constexpr uint32_t W_NEG_R = plant_const(NEG_R);                          // plant(a, W_NEG_R) = -a * 2^32 mod q
+
+// The two halves of plant(), apart so that a stage can issue them grouped by kind. UNIFORM_W: W lives in an SGPR.
+template <bool UNIFORM_W>
+__device__ __forceinline__ uint32_t plant_lo(uint32_t a, uint32_t W)
+{
+  uint32_t X;
+  if constexpr (UNIFORM_W)
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(X) : "v"(a), "s"(W));
+  else
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(X) : "v"(a), "v"(W));
+  return X;
+}
+__device__ __forceinline__ uint32_t plant_hi(uint32_t X)
+{
+  uint32_t r;
+  asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(X), "s"(Q));  // named: left to itself hipcc turns a multiplication by the constant q into shifts and adds
+  return r;
+}
+// 0 <= a < PLANT_LIMIT  ->  (a * w) mod q, canonical.
+template <bool UNIFORM_W = true>
+__device__ __forceinline__ uint32_t plant(uint32_t a, uint32_t W) { return plant_hi(plant_lo<UNIFORM_W>(a, W)); }
+// a * b < 2^32  ->  -(a * b) * 2^-32 mod q, canonical (one factor carries -2^32 beforehand, or the constant is folded elsewhere).
+__device__ __forceinline__ uint32_t plant2(uint32_t a, uint32_t b) { return plant_hi(plant_lo<true>(a * b, QINV32)); }
 
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 
@@ -59,15 +94,9 @@ __device__ __forceinline__ int32_t msub_q(int32_t qh, int32_t p)
   return r;
 }
 
-// |x| < 2^19  ->  (x * w) mod q as a value in [0, q].
-__device__ __forceinline__ int32_t shoup(int32_t x, int32_t w, int32_t wp)
-{
-  return msub_q(mulhi_i32<false>(x, wp), __mul24(x, w));
-}
-
-// |x| < 2^22  ->  x mod q as a value in [0, q] (the companion of w = 1 is off by only 0.04, so the
-// range is wider than shoup's). The instruction is named because hipcc otherwise picks the 64-bit
-// v_mad_u64_u32 here; the multiplier must be wave-uniform (SGPR operand).
+// |x| < 2^22  ->  x mod q as a value in [0, q]: signed Barrett, x - floor(x * round(2^32/q) / 2^32) * q (the
+// multiplier is off by only 0.04, so the quotient is exact or one short). The instruction is named because hipcc
+// otherwise picks the 64-bit v_mad_u64_u32 here; the multiplier must be wave-uniform (SGPR operand).
 __device__ __forceinline__ int32_t reduce(int32_t x)
 {
   return msub_q(mulhi_i32<true>(x, RQ32), x);
@@ -90,16 +119,6 @@ __device__ __forceinline__ int32_t mulmod(int32_t a, int32_t b)
   const uint32_t p = mul24((uint32_t)a, (uint32_t)b);                   // <= q^2 < 2^28
   const uint32_t qh = __umulhi(p, 349496u);                            // floor(p/q) or one less
   return (int32_t)csub((uint32_t)mad_i24((int32_t)qh, -QI, (int32_t)p), Q);
-}
-
-// |a * b| < 2^31 (e.g. a in [0, q], |b| < 2^17)  ->  (a*b) mod q as a value in (-q/60, q + q/60): the signed
-// Barrett quotient mulhi(p, round(2^32/q)) is off by at most one when p/q is within 2^31 * 0.04 / 2^32 < 1/50
-// of an integer. Three instructions; good enough as input of the inverse transform, whose first Shoup
-// multiplication and reductions take any |x| < 2^19.
-__device__ __forceinline__ int32_t mulmod_lazy(int32_t a, int32_t b)
-{
-  const int32_t p = a * b;
-  return msub_q(mulhi_i32<true>(p, RQ32), p);
 }
 
 }  // namespace fa

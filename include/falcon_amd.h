@@ -133,20 +133,23 @@ int fa_verify_many_dev(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, c
  * settled by a host-side loop but by one more pass enqueued behind the batch, with twice the blocks, for at most
  * min(4096, half the pass size) such items. fa_finish synchronises `stream` and reports how many items of the calls
  * since the last fa_finish even that pass left unresolved (their accept byte is 0): returns 0 if none, else
- * FA_E_UNRESOLVED with the count in *unresolved (nullable) -- verify those batches again synchronously. No reference
- * counterpart: the reference is synchronous by nature. */
+ * FA_E_UNRESOLVED with the count in *unresolved (nullable) -- verify those batches again synchronously. The count is
+ * per context: with asynchronous calls of one context in flight on several streams, an item is reported by the
+ * fa_finish that follows its own pass, whichever stream that names. No reference counterpart: the reference is
+ * synchronous by nature. */
 int fa_finish(fa_ctx* ctx, void* stream, uint64_t* unresolved);
 
-/* The same as fa_verify_many_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc): NO COUNTERPART IN THE REFERENCE. The pipeline's workspace is a
- * static device array of the library (about 18 MB, held by every GPU the library runs on until the process ends)
- * instead of buffers of the context, so the call makes no hipMalloc / hipFree and uses no allocating routine.
+/* The same as fa_verify_many_dev for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc): NO COUNTERPART IN THE REFERENCE. The pipeline's workspace is a static device array of the
+ * library (about 18 MB, held by every GPU the library runs on until the process ends) instead of buffers of the
+ * context, so the call makes no hipMalloc / hipFree and uses no allocating routine.
  * Limits: count <= FA_NOALLOC_MAX_ITEMS (else FA_E_TOO_MANY); reference wire format; at most 17 hash blocks per
  * item; no debug outputs. Items short of SHAKE256 blocks are settled by the device-side retry pass described at
  * fa_finish; the call synchronises `stream` once and returns FA_E_UNRESOLVED if any item is left (probability
- * ~1e-50 per item). All calls on one GPU -- from any context -- share that GPU's array, which keeps the previous
- * call's contents (every call clears the counters it needs): calls that overlap on one GPU race; calls through one
- * context are ordered by the library as described above. */
+ * ~1e-50 per item). Because of that synchronisation (and a host-side counter it reads) the call is NOT for use under
+ * HIP stream capture. All calls on one GPU -- from any context -- share that GPU's array, which keeps the previous
+ * call's contents (every call clears the counters it needs); the library takes a per-GPU lock for the duration of the
+ * call, so calls from several host threads (each through its own context) are safe and run one after the other. */
 #define FA_NOALLOC_MAX_ITEMS 4096
 int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_t* pk, const uint8_t* msg,
                                const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy,
@@ -155,8 +158,8 @@ int fa_verify_many_dev_noalloc(fa_ctx* ctx, int logn, size_t count, const uint8_
 /* ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
  * For callers that keep public keys decoded and verify many signatures per key (falcon.hpp:226-229,
  * benchmarks/bench_signing.cpp:105). A key is prepared once -- decoded and carried into the NTT domain,
- * N uint16 values in this library's own coefficient order (an opaque blob of fa_prepared_key_len bytes,
- * valid for any context of the same logn) -- and items then name their key by index. Per item this saves
+ * N uint16 values in this library's own coefficient order and scaling (an opaque blob of fa_prepared_key_len bytes,
+ * valid for any context of the same logn and the same build of the library) -- and items then name their key by index. Per item this saves
  * the key unpacking and one of the two forward transforms, and 897/1793 bytes of input.
  *
  * fa_prepare_keys: exactly one of `pk` (nkeys encoded keys, decode_pkey, decoding.hpp:18-48; a key with a
@@ -174,6 +177,29 @@ int fa_verify_many_prepared(fa_ctx* ctx, int logn, size_t count, const uint16_t*
 int fa_verify_many_prepared_dev(fa_ctx* ctx, int logn, size_t count, const uint16_t* prepared, const uint32_t* key_idx,
                                 const uint8_t* msg, const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig,
                                 int norm_policy, uint8_t* accept, const fa_debug* dbg, void* stream);
+
+/* ---- resident key sets: the decoded-key form for HOST callers (falcon.hpp:226-229, verification.hpp:20-26,
+ * benchmarks/bench_signing.cpp:105: a caller that keeps `h` across calls) ----
+ * fa_verify_many_prepared takes the prepared keys from caller memory and uploads them with every call -- N uint16 per
+ * key, more bytes than the packed key it replaces. A key set keeps them in the GPU's memory instead: created once
+ * from nkeys encoded keys (`pk`) or decoded polynomials (`h`), exactly one of the two as for fa_prepare_keys, it is
+ * then named by any number of fa_verify_many_keyset calls, which send only signatures, messages and 4-byte key
+ * indices over the host link (702 instead of 1,595 bytes per Falcon-512 item with a 32-byte message), through the same
+ * two-set staging pipeline as fa_verify_many. key_idx == NULL: item i uses key i (needs nkeys >= count); every index is
+ * checked against nkeys (FA_E_ARG). The set belongs to the GPU of the context that created it and may be used through
+ * any context of that GPU (FA_E_ARG otherwise), from several threads at once (it is read-only); destroy it when no call
+ * that names it is running. fa_keyset_device_keys: the device pointer of the prepared keys, for the device-resident
+ * calls (fa_verify_many_prepared_dev). Wire format: the one in force in `ctx` when the set is created (keys) and when
+ * it is used (signatures). */
+typedef struct fa_keyset fa_keyset;
+int fa_keyset_create(fa_ctx* ctx, int logn, size_t nkeys, const uint8_t* pk, const uint16_t* h, fa_keyset** out);
+void fa_keyset_destroy(fa_keyset* ks);
+size_t fa_keyset_size(const fa_keyset* ks);
+int fa_keyset_logn(const fa_keyset* ks);
+const uint16_t* fa_keyset_device_keys(const fa_keyset* ks);
+int fa_verify_many_keyset(fa_ctx* ctx, const fa_keyset* ks, size_t count, const uint32_t* key_idx, const uint8_t* msg,
+                          const uint64_t* msg_off, uint32_t mlen, const uint8_t* sig, int norm_policy, uint8_t* accept,
+                          const fa_debug* dbg);
 
 /* ---- hashing::hash_to_point<n>(salt, 40, msg, mlen, poly), hashing.hpp:16-50, as a batched primitive ----
  * (also the first step of signing, signing.hpp:48-49). salt: count*40 bytes; messages as in fa_verify_many;

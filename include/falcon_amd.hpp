@@ -9,6 +9,10 @@
 //   falcon::verify_many<N>(count, pkeys, msgs, ...)    no counterpart: `count` independent calls of the above
 //   falcon::prepared_keys<N> + verify_many<N>(count, keys, key_idx, ...)
 //                                                      verification.hpp:20-26   verify with the key kept decoded
+//   falcon::resident_keys<N> + verify_many<N>(count, keys, key_idx, ...)
+//                                                      the same with the keys kept in the GPU's memory across calls
+//   falcon::verify_many_sharded<N> / verify_many_sharded_device<N>
+//                                                      no counterpart: one batch over several GPUs, host or device buffers
 //   falcon::hash_to_point_many<N>(count, salts, ...)   hashing.hpp:16-50
 //   falcon::compute_public_keys<N>(count, f, g, h)     keygen.hpp:67-90
 //   falcon::ntt_many<N> / intt_many<N>(count, a, out)  ntt.hpp:120-150 / 161-200
@@ -268,6 +272,80 @@ inline void verify_many_sharded(size_t count, const uint8_t* pkeys, const uint8_
   verify_many_sharded<N>(count, pkeys, msgs, mlen, msg_off, sigs, accept, devices, policy, wire);
 }
 
+// Multi-GPU form for batches that already live in the GPUs' memory (one host thread, one
+// context and one queue per GPU): every shard names its device and its own device-resident arrays, laid out as
+// verify_many_device takes them. One host thread per distinct device enqueues all of that device's shards
+// asynchronously (FA_OPT_ASYNC) on the device's default stream and waits once (fa_finish); a shard the device-side
+// retry pass could not settle (probability ~1e-50 per item) is verified again synchronously. No host staging, no
+// collective: N GPUs run at N times the device-resident rate. The first error is rethrown after all devices finished.
+struct device_shard {
+  int device = 0;
+  size_t count = 0;
+  const uint8_t* d_pkeys = nullptr;
+  const uint8_t* d_msgs = nullptr;
+  const uint64_t* d_msg_off = nullptr;  // nullable: fixed-length messages
+  const uint8_t* d_sigs = nullptr;
+  uint8_t* d_accept = nullptr;
+};
+template<size_t N>
+inline void verify_many_sharded_device(const std::vector<device_shard>& shards, size_t mlen, norm_policy policy = norm_policy::exact)
+{
+  std::vector<int> devices;  // distinct devices, in order of first appearance
+  for (const device_shard& sh : shards) {
+    bool seen = false;
+    for (int d : devices) seen |= d == sh.device;
+    if (!seen) devices.push_back(sh.device);
+  }
+  const uint32_t ml = detail::msg_len(mlen);
+  std::vector<std::exception_ptr> errors(devices.size());
+  auto run_device = [&](size_t g) noexcept {
+    try {
+      detail::shared_context& sc = detail::shared_context_for(devices[g]);
+      std::lock_guard<std::mutex> hold(sc.lock);
+      if (!sc.ctx) {
+        const int rc = fa_ctx_create(devices[g], &sc.ctx);
+        if (rc) throw device_error("fa_ctx_create", rc);
+      }
+      int rc = fa_set_option(sc.ctx, FA_OPT_WIRE_FORMAT, FA_WIRE_REFERENCE);
+      if (!rc) rc = fa_set_option(sc.ctx, FA_OPT_ASYNC, 1);
+      if (rc) throw device_error("fa_set_option", rc);
+      int first = 0;
+      for (const device_shard& sh : shards)
+        if (sh.device == devices[g] && !first)
+          first = fa_verify_many_dev(sc.ctx, detail::logn<N>(), sh.count, sh.d_pkeys, sh.d_msgs, sh.d_msg_off, ml, sh.d_sigs, (int)policy,
+                                     sh.d_accept, nullptr, nullptr);
+      uint64_t unresolved = 0;
+      const int rf = fa_finish(sc.ctx, nullptr, &unresolved);  // also after a failure: nothing of this call stays in flight
+      (void)fa_set_option(sc.ctx, FA_OPT_ASYNC, 0);
+      if (first) throw device_error("fa_verify_many_dev", first);
+      if (rf == FA_E_UNRESOLVED) {  // settle the stragglers with the synchronising call (its host loop takes any number of blocks)
+        for (const device_shard& sh : shards)
+          if (sh.device == devices[g]) {
+            rc = fa_verify_many_dev(sc.ctx, detail::logn<N>(), sh.count, sh.d_pkeys, sh.d_msgs, sh.d_msg_off, ml, sh.d_sigs, (int)policy,
+                                    sh.d_accept, nullptr, nullptr);
+            if (rc) throw device_error("fa_verify_many_dev", rc);
+          }
+      } else if (rf) {
+        throw device_error("fa_finish", rf);
+      }
+    } catch (...) {
+      errors[g] = std::current_exception();
+    }
+  };
+  std::vector<std::thread> workers;
+  size_t started = 1;  // the calling thread takes the first device
+  try {
+    workers.reserve(devices.size());
+    for (; started < devices.size(); started++) workers.emplace_back(run_device, started);
+  } catch (...) {  // threads that could not be started: their devices run inline below
+  }
+  if (!devices.empty()) run_device(0);
+  for (auto& w : workers) w.join();
+  for (size_t g = started; g < devices.size(); g++) run_device(g);
+  for (auto& e : errors)
+    if (e) std::rethrow_exception(e);
+}
+
 // ---- decoded-key form: verification::verify<N, beta2>(h, msg, mlen, sig), verification.hpp:20-26 ----
 // Keys are prepared once (decoded + forward NTT, kept in HBM-friendly uint16 form on the host side here)
 // and reused for any number of signatures; beta2 is implied by N (falcon.hpp:245-246).
@@ -309,6 +387,60 @@ inline void verify_many(size_t count, const prepared_keys<N>& keys, const uint32
   const int rc = fa_verify_many_prepared(detail::context(device), detail::logn<N>(), count, keys.data(), keys.size(), key_idx,
                                          msgs, msg_off, detail::msg_len(mlen), sigs, (int)policy, accept, nullptr);
   if (rc) throw device_error("fa_verify_many_prepared", rc);
+}
+
+// The decoded-key form for callers that keep their keys ACROSS calls (falcon.hpp:226-229; benchmarks/bench_signing.cpp:105
+// keeps `h` for the whole run): the prepared keys stay in the memory of GPU `device` (fa_keyset), and a verify_many call
+// sends only signatures, messages and 4-byte key indices over the host link -- 702 instead of 1,595 bytes per Falcon-512
+// item with a 32-byte message. prepared_keys<N> above holds the same data in host memory and uploads it with every call.
+template<size_t N>
+class resident_keys
+{
+public:
+  static resident_keys from_encoded(size_t nkeys, const uint8_t* pkeys, int device = 0)
+  {
+    return resident_keys(nkeys, pkeys, nullptr, device);
+  }
+  static resident_keys from_decoded(size_t nkeys, const uint16_t* h, int device = 0)
+  {
+    return resident_keys(nkeys, nullptr, h, device);
+  }
+  resident_keys(const resident_keys&) = delete;
+  resident_keys& operator=(const resident_keys&) = delete;
+  resident_keys(resident_keys&& o) noexcept : ks_(o.ks_), device_(o.device_) { o.ks_ = nullptr; }
+  resident_keys& operator=(resident_keys&& o) noexcept
+  {
+    if (this != &o) {
+      fa_keyset_destroy(ks_);
+      ks_ = o.ks_, device_ = o.device_;
+      o.ks_ = nullptr;
+    }
+    return *this;
+  }
+  ~resident_keys() { fa_keyset_destroy(ks_); }
+  size_t size() const { return fa_keyset_size(ks_); }
+  int device() const { return device_; }
+  const fa_keyset* handle() const { return ks_; }
+  const uint16_t* device_data() const { return fa_keyset_device_keys(ks_); }  // for verify_many_prepared_dev-style callers
+
+private:
+  resident_keys(size_t nkeys, const uint8_t* pkeys, const uint16_t* h, int device) : device_(device)
+  {
+    const int rc = fa_keyset_create(detail::context(device), detail::logn<N>(), nkeys, pkeys, h, &ks_);
+    if (rc) throw device_error("fa_keyset_create", rc);
+  }
+  fa_keyset* ks_ = nullptr;
+  int device_ = 0;
+};
+
+// Item i is checked against keys[key_idx[i]] (key_idx == nullptr: against keys[i]); runs on the GPU that holds the keys.
+template<size_t N>
+inline void verify_many(size_t count, const resident_keys<N>& keys, const uint32_t* key_idx, const uint8_t* msgs, size_t mlen,
+                        const uint64_t* msg_off, const uint8_t* sigs, uint8_t* accept, norm_policy policy = norm_policy::exact)
+{
+  const int rc = fa_verify_many_keyset(detail::context(keys.device()), keys.handle(), count, key_idx, msgs, msg_off,
+                                       detail::msg_len(mlen), sigs, (int)policy, accept, nullptr);
+  if (rc) throw device_error("fa_verify_many_keyset", rc);
 }
 
 // hashing::hash_to_point<N>(salt, 40, msg, mlen, poly) (hashing.hpp:16-50) for `count` (salt, message) pairs.
@@ -400,11 +532,15 @@ public:
   bool verify(const uint8_t* pkey, const uint8_t* msg, uint32_t mlen, const uint8_t* sig)
   {
     request r{ pkey, msg, mlen, sig, 0, 0, { false } };
-    lock();
-    pending_.push_back(&r);
-    bool lead = !busy_.load(std::memory_order_relaxed);
-    if (lead) busy_.store(true, std::memory_order_relaxed);
-    unlock();
+    bool lead;
+    {
+      queue_guard hold(*this);  // released on every way out, an exception from the push included
+      pending_.push_back(&r);
+      // acquire: the thread that takes the lead must see everything the previous leader wrote (batch_, the gather
+      // buffers, last_batch_) before it released busy_
+      lead = !busy_.load(std::memory_order_acquire);
+      if (lead) busy_.store(true, std::memory_order_relaxed);
+    }
     while (!lead) {
       // Wait for the result or for the leader's place. A batch takes 50-100 us, a sleeping thread about as long to be
       // woken: watch the two flags for a while, then poll at intervals.
@@ -416,10 +552,9 @@ public:
           std::this_thread::sleep_for(std::chrono::microseconds(50));
       }
       if (r.done.load(std::memory_order_acquire)) break;  // served: leaves without touching the queue again
-      lock();
-      lead = !r.done.load(std::memory_order_acquire) && !busy_.load(std::memory_order_relaxed);
+      queue_guard hold(*this);
+      lead = !r.done.load(std::memory_order_acquire) && !busy_.load(std::memory_order_acquire);
       if (lead) busy_.store(true, std::memory_order_relaxed);
-      unlock();
     }
     if (lead) {  // batches until this thread's own request has been served (normally the first one taken)
       while (!r.done.load(std::memory_order_relaxed)) {
@@ -428,14 +563,21 @@ public:
           while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(5)) relax();
         }
         batch_.clear();
-        size_t bytes = 0;
-        lock();
-        while (!pending_.empty() && batch_.size() < MAX_BATCH && bytes <= MAX_MSG_BYTES) {
-          bytes += pending_.front()->mlen;
-          batch_.push_back(pending_.front());
-          pending_.pop_front();
+        try {
+          batch_.reserve(MAX_BATCH);  // outside the queue's lock: the pushes below cannot throw
+        } catch (...) {
+          fail_own(r);  // out of memory: this thread's request fails, the lead passes on
+          break;
         }
-        unlock();
+        size_t bytes = 0;
+        {
+          queue_guard hold(*this);
+          while (!pending_.empty() && batch_.size() < MAX_BATCH && bytes <= MAX_MSG_BYTES) {
+            bytes += pending_.front()->mlen;
+            batch_.push_back(pending_.front());
+            pending_.pop_front();
+          }
+        }
         run();
         last_batch_ = batch_.size();
         for (request* q : batch_) q->done.store(true, std::memory_order_release);  // *q may be gone right after this store
@@ -446,11 +588,11 @@ public:
     return r.ok != 0;
   }
 
-  // batches run and requests served so far (diagnostics)
+  // batches run and requests served so far (diagnostics; may be read while other threads are calling)
   void stats(uint64_t* batches, uint64_t* requests, double* run_us = nullptr) const
   {
-    *batches = batches_, *requests = requests_;
-    if (run_us) *run_us = run_us_;
+    *batches = batches_.load(std::memory_order_relaxed), *requests = requests_.load(std::memory_order_relaxed);
+    if (run_us) *run_us = (double)run_ns_.load(std::memory_order_relaxed) * 1e-3;
   }
 
 private:
@@ -477,7 +619,7 @@ private:
   {
     int rc = 0;
     const size_t n = batch_.size();
-    batches_++, requests_ += n;
+    batches_.fetch_add(1, std::memory_order_relaxed), requests_.fetch_add(n, std::memory_order_relaxed);
     const auto t_run = std::chrono::steady_clock::now();
     try {
       pk_.resize(n * pkey_len_), sig_.resize(n * sig_len_), off_.resize(n + 1), acc_.assign(n, 0);
@@ -500,7 +642,21 @@ private:
       rc = FA_E_INTERNAL;
     }
     for (size_t i = 0; i < n; i++) batch_[i]->ok = rc ? 0 : acc_[i], batch_[i]->rc = rc;
-    run_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run).count();
+    run_ns_.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_run).count(),
+                      std::memory_order_relaxed);
+  }
+
+  // The leader could not even reserve its batch: take its own request out of the queue (if it is still there) and fail it.
+  void fail_own(request& r)
+  {
+    queue_guard hold(*this);
+    for (auto it = pending_.begin(); it != pending_.end(); ++it)
+      if (*it == &r) {
+        pending_.erase(it);
+        r.rc = FA_E_INTERNAL;
+        r.done.store(true, std::memory_order_release);
+        break;
+      }
   }
 
   static constexpr size_t pkey_len_ = 1 + 14 * N / 8, sig_len_ = N == 512 ? 666 : 1280;
@@ -511,14 +667,21 @@ private:
     while (qlock_.test_and_set(std::memory_order_acquire)) relax();
   }
   void unlock() { qlock_.clear(std::memory_order_release); }
+  struct queue_guard {  // the spin lock as a scope
+    call_combiner& c;
+    explicit queue_guard(call_combiner& cc) : c(cc) { c.lock(); }
+    ~queue_guard() { c.unlock(); }
+    queue_guard(const queue_guard&) = delete;
+    queue_guard& operator=(const queue_guard&) = delete;
+  };
   std::atomic_flag qlock_ = ATOMIC_FLAG_INIT;
   std::deque<request*> pending_;
   std::atomic<bool> busy_{ false };
   std::vector<request*> batch_;
   std::vector<uint8_t> pk_, sig_, msg_, acc_;
   std::vector<uint64_t> off_;
-  uint64_t batches_ = 0, requests_ = 0;
-  double run_us_ = 0;  // time spent inside run()
+  std::atomic<uint64_t> batches_{ 0 }, requests_{ 0 };
+  std::atomic<uint64_t> run_ns_{ 0 };  // time spent inside run()
   size_t last_batch_ = 0;  // size of the previous batch: more than one means other threads are calling too
 };
 

@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>  // device buffers for verify_many_sharded_device (the library's own headers need no HIP)
+
 #include "falcon_amd.hpp"
 
 static std::vector<uint8_t> slurp(const char* path)
@@ -134,6 +136,82 @@ static int run(size_t count, size_t mlen, std::vector<uint8_t>& pk, std::vector<
     falcon::verify_many<N>(count, keys, nullptr, msg.data(), mlen, nullptr, sig.data(), acc3.data());
     for (uint8_t a : acc3) std::putchar('0' + a);
     std::putchar('\n');
+  }
+  stage("resident keys");
+  {  // the same keys kept on the GPU (fa_keyset): item i against key i, then five keys shared by all items through an index
+    auto rk = falcon::resident_keys<N>::from_encoded(count, pk.data());
+    std::vector<uint8_t> a(count, 7);
+    falcon::verify_many<N>(count, rk, nullptr, msg.data(), mlen, nullptr, sig.data(), a.data());
+    if (a != acc) {
+      std::fprintf(stderr, "resident_keys: differs from verify_many\n");
+      return 8;
+    }
+    const size_t nk = count < 5 ? count : 5;
+    std::vector<uint32_t> idx(count);
+    for (size_t i = 0; i < count; i++) idx[i] = (uint32_t)(i % nk);
+    auto hk = falcon::prepared_keys<N>::from_encoded(nk, pk.data());
+    auto rk5 = falcon::resident_keys<N>::from_encoded(nk, pk.data());
+    std::vector<uint8_t> want(count, 7), got(count, 9);
+    falcon::verify_many<N>(count, hk, idx.data(), msg.data(), mlen, nullptr, sig.data(), want.data());
+    falcon::verify_many<N>(count, rk5, idx.data(), msg.data(), mlen, nullptr, sig.data(), got.data());
+    if (want != got || !std::equal(got.begin(), got.begin() + (std::ptrdiff_t)nk, acc.begin())) {
+      std::fprintf(stderr, "resident_keys with an index: differs from prepared_keys\n");
+      return 8;
+    }
+    bool threw = false;  // an index past the set is refused
+    idx[count / 2] = (uint32_t)nk;
+    try {
+      falcon::verify_many<N>(count, rk5, idx.data(), msg.data(), mlen, nullptr, sig.data(), got.data());
+    } catch (const falcon::device_error&) {
+      threw = true;
+    }
+    if (!threw) {
+      std::fprintf(stderr, "resident_keys: key index out of range accepted\n");
+      return 8;
+    }
+  }
+  stage("verify_many_sharded_device");
+  {  // device-resident shards: the batch cut in two (and in three) ranges, all on GPU 0 -- the multi-GPU path's host logic
+    uint8_t *d_pk = nullptr, *d_msg = nullptr, *d_sig = nullptr, *d_acc = nullptr;
+    auto hip_ok = [](hipError_t e) { return e == hipSuccess; };
+    if (!hip_ok(hipMalloc((void**)&d_pk, pk.size() + 8)) || !hip_ok(hipMalloc((void**)&d_msg, msg.size() + 8)) ||
+        !hip_ok(hipMalloc((void**)&d_sig, sig.size() + 8)) || !hip_ok(hipMalloc((void**)&d_acc, count + 8)) ||
+        !hip_ok(hipMemcpy(d_pk, pk.data(), pk.size(), hipMemcpyHostToDevice)) ||
+        !hip_ok(hipMemcpy(d_msg, msg.data(), msg.size(), hipMemcpyHostToDevice)) ||
+        !hip_ok(hipMemcpy(d_sig, sig.data(), sig.size(), hipMemcpyHostToDevice))) {
+      std::fprintf(stderr, "device buffers: HIP error\n");
+      return 9;
+    }
+    for (size_t parts : { (size_t)1, (size_t)2, (size_t)3 }) {
+      // ranges start at multiples of 4 items so that every shard's arrays stay 4-byte aligned (fa_verify_many_dev)
+      const size_t per = ((count + parts - 1) / parts + 3) & ~(size_t)3;
+      std::vector<falcon::device_shard> shards;
+      for (size_t lo = 0; lo < count; lo += per) {
+        const size_t n = std::min(per, count - lo);
+        shards.push_back(falcon::device_shard{ 0, n, d_pk + lo * falcon::pkey_len<N>(), d_msg + lo * mlen, nullptr,
+                                               d_sig + lo * falcon::sig_len<N>(), d_acc + lo });
+      }
+      if (!hip_ok(hipMemset(d_acc, 7, count))) return 9;
+      falcon::verify_many_sharded_device<N>(shards, mlen);
+      std::vector<uint8_t> got(count, 9);
+      if (!hip_ok(hipMemcpy(got.data(), d_acc, count, hipMemcpyDeviceToHost))) return 9;
+      if (got != acc) {
+        std::fprintf(stderr, "verify_many_sharded_device over %zu shards differs from verify_many\n", shards.size());
+        return 9;
+      }
+    }
+    bool threw = false;  // a device that does not exist: the error surfaces after the good device's shard has run
+    try {
+      std::vector<falcon::device_shard> shards{ { 0, count, d_pk, d_msg, nullptr, d_sig, d_acc }, { 63, count, d_pk, d_msg, nullptr, d_sig, d_acc } };
+      falcon::verify_many_sharded_device<N>(shards, mlen);
+    } catch (const falcon::device_error&) {
+      threw = true;
+    }
+    (void)hipFree(d_pk), (void)hipFree(d_msg), (void)hipFree(d_sig), (void)hipFree(d_acc);
+    if (!threw) {
+      std::fprintf(stderr, "verify_many_sharded_device: missing device not reported\n");
+      return 9;
+    }
   }
   stage("verify_many_sharded");
   std::vector<uint8_t> acc2(count, 7);

@@ -165,3 +165,44 @@ def test_two_streams_share_one_context(ctx, oracle, corpus):
         np.testing.assert_array_equal(d_s2.cpu().numpy(), s2_ref)
         np.testing.assert_array_equal(d_salt.cpu().numpy(), salt_ref)
         np.testing.assert_array_equal(acc.cpu().numpy(), want2)
+
+
+def test_failed_call_leaves_the_workspace_fence_whole(oracle, corpus):
+    """A call that fails after it has begun using the context's workspace -- a tag array with a wrong tag, found only
+    after the partition kernels ran; a key buffer of an absurd size in the specification wire format -- must still leave
+    the fence behind what it enqueued: good calls on ANOTHER stream of the same context follow, and match the oracle."""
+    torch, dev = _torch()
+    from falcon_amd import capi
+    c = capi.Context(0)
+    try:
+        pk, msg, sig, _ = corpus.generate(9, 3000, seed=123, malformed_permille=300, threads=16)
+        want = oracle.verify_many(9, pk, msg, sig, threads=16)[0] & 1
+        t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (pk, msg, sig)]
+        acc = torch.zeros(3000, dtype=torch.uint8, device=dev)
+        s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        # (1) mixed batch with a tag that is neither 9 nor 10
+        n = 5000
+        tags = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        tags[n // 2] = 11
+        off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        with pytest.raises(capi.FalconAmdError) as e:
+            c.verify_mixed_dev(n, tags.data_ptr(), t[0].data_ptr(), off.data_ptr(), t[1].data_ptr(), off.data_ptr(), t[2].data_ptr(),
+                               off.data_ptr(), acc.data_ptr(), stream=s1.cuda_stream)
+        assert e.value.code == capi.E_LOGN
+        c.verify_many_dev(9, 3000, t[0].data_ptr(), t[1].data_ptr(), None, 32, t[2].data_ptr(), acc.data_ptr(), stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(acc.cpu().numpy(), want)
+        # (2) specification wire format: the repacked keys of 2^32 - 1 items do not fit any GPU; the call fails in its reserve
+        c.set_option(capi.OPT_WIRE_FORMAT, capi.WIRE_SPEC)
+        with pytest.raises(capi.FalconAmdError):
+            c.verify_many_dev(9, 0xFFFFFFFF, t[0].data_ptr(), t[1].data_ptr(), None, 32, t[2].data_ptr(), acc.data_ptr(), stream=s1.cuda_stream)
+        c.set_option(capi.OPT_WIRE_FORMAT, capi.WIRE_REFERENCE)
+        acc.fill_(7)
+        torch.cuda.synchronize()
+        c.verify_many_dev(9, 3000, t[0].data_ptr(), t[1].data_ptr(), None, 32, t[2].data_ptr(), acc.data_ptr(), stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(acc.cpu().numpy(), want)
+    finally:
+        c.close()
