@@ -250,6 +250,7 @@ static const uint64_t KECCAK_RC[24] = {
   0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
   0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL
 };
+#ifndef FO_NATIVE
 static const unsigned KECCAK_ROT[25] = { 0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3,  10, 43,
                                          25, 39, 41, 45, 15, 21, 8,  18, 2,  61, 56, 14 };
 
@@ -272,12 +273,62 @@ static void keccak_f1600(uint64_t a[25])
     a[0] ^= KECCAK_RC[round];
   }
 }
+#else
+/* FO_NATIVE (the TIMED cpu_baseline build of bench.py, oracle/Makefile target `native`: -O3 -march=native on the box
+ * that runs it): the same permutation with the 25 lanes in locals and every index a constant, so that the compiler
+ * keeps the state in registers -- what an optimised SHAKE256 such as the reference's sha3 submodule does. Same
+ * function, checked against the loop form above by every test that loads this build (tests/test_oracle_native.py). */
+#define FO_ROL(x, r) (((x) << (r)) | ((x) >> (64 - (r))))
+static void keccak_f1600(uint64_t a[25])
+{
+  uint64_t a00 = a[0], a01 = a[1], a02 = a[2], a03 = a[3], a04 = a[4], a05 = a[5], a06 = a[6], a07 = a[7], a08 = a[8],
+           a09 = a[9], a10 = a[10], a11 = a[11], a12 = a[12], a13 = a[13], a14 = a[14], a15 = a[15], a16 = a[16],
+           a17 = a[17], a18 = a[18], a19 = a[19], a20 = a[20], a21 = a[21], a22 = a[22], a23 = a[23], a24 = a[24];
+  for (int round = 0; round < 24; round++) {
+    const uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
+                   c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
+    const uint64_t d0 = c4 ^ FO_ROL(c1, 1), d1 = c0 ^ FO_ROL(c2, 1), d2 = c1 ^ FO_ROL(c3, 1), d3 = c2 ^ FO_ROL(c4, 1),
+                   d4 = c3 ^ FO_ROL(c0, 1);
+    /* theta, then rho + pi: b[y + 5 ((2x + 3y) mod 5)] = rol(a[x + 5y] ^ d[x], ROT[x + 5y]) */
+    const uint64_t b00 = a00 ^ d0, b10 = FO_ROL(a01 ^ d1, 1), b20 = FO_ROL(a02 ^ d2, 62), b05 = FO_ROL(a03 ^ d3, 28),
+                   b15 = FO_ROL(a04 ^ d4, 27), b16 = FO_ROL(a05 ^ d0, 36), b01 = FO_ROL(a06 ^ d1, 44), b11 = FO_ROL(a07 ^ d2, 6),
+                   b21 = FO_ROL(a08 ^ d3, 55), b06 = FO_ROL(a09 ^ d4, 20), b07 = FO_ROL(a10 ^ d0, 3), b17 = FO_ROL(a11 ^ d1, 10),
+                   b02 = FO_ROL(a12 ^ d2, 43), b12 = FO_ROL(a13 ^ d3, 25), b22 = FO_ROL(a14 ^ d4, 39), b23 = FO_ROL(a15 ^ d0, 41),
+                   b08 = FO_ROL(a16 ^ d1, 45), b18 = FO_ROL(a17 ^ d2, 15), b03 = FO_ROL(a18 ^ d3, 21), b13 = FO_ROL(a19 ^ d4, 8),
+                   b14 = FO_ROL(a20 ^ d0, 18), b24 = FO_ROL(a21 ^ d1, 2), b09 = FO_ROL(a22 ^ d2, 61), b19 = FO_ROL(a23 ^ d3, 56),
+                   b04 = FO_ROL(a24 ^ d4, 14);
+    /* chi, iota */
+    a00 = b00 ^ (~b01 & b02) ^ KECCAK_RC[round]; a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
+    a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
+    a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
+    a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
+    a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
+  }
+  a[0] = a00; a[1] = a01; a[2] = a02; a[3] = a03; a[4] = a04; a[5] = a05; a[6] = a06; a[7] = a07; a[8] = a08; a[9] = a09;
+  a[10] = a10; a[11] = a11; a[12] = a12; a[13] = a13; a[14] = a14; a[15] = a15; a[16] = a16; a[17] = a17; a[18] = a18; a[19] = a19;
+  a[20] = a20; a[21] = a21; a[22] = a22; a[23] = a23; a[24] = a24;
+}
+#endif
 
 static void shake_init(fo_shake256* h) { memset(h, 0, sizeof(*h)); }
 
 static void shake_absorb(fo_shake256* h, const uint8_t* p, size_t len)
 {
-  for (size_t i = 0; i < len; i++) {
+  size_t i = 0;
+#if defined(FO_NATIVE) && defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+  /* whole 64-bit lanes at a time wherever the position is lane-aligned (little-endian host: a lane is its 8 bytes) */
+  for (; i < len && (h->pos & 7); i++) {
+    h->s[h->pos >> 3] ^= (uint64_t)p[i] << (8 * (h->pos & 7));
+    if (++h->pos == FO_RATE) { keccak_f1600(h->s); h->pos = 0; }
+  }
+  for (; len - i >= 8; i += 8) {
+    uint64_t lane;
+    memcpy(&lane, p + i, 8);
+    h->s[h->pos >> 3] ^= lane;
+    if ((h->pos += 8) == FO_RATE) { keccak_f1600(h->s); h->pos = 0; }
+  }
+#endif
+  for (; i < len; i++) {
     h->s[h->pos >> 3] ^= (uint64_t)p[i] << (8 * (h->pos & 7));
     if (++h->pos == FO_RATE) { keccak_f1600(h->s); h->pos = 0; }
   }
@@ -294,7 +345,19 @@ static void shake_finalize(fo_shake256* h)
 
 static void shake_read(fo_shake256* h, uint8_t* out, size_t len)
 {
-  for (size_t i = 0; i < len; i++) {
+  size_t i = 0;
+#if defined(FO_NATIVE) && defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+  while (i < len && !(h->pos & 7)) {  /* lane-aligned: copy what is left of the block, whole lanes */
+    if (h->pos == FO_RATE) { keccak_f1600(h->s); h->pos = 0; }
+    size_t take = FO_RATE - h->pos;
+    if (take > len - i) take = (len - i) & ~(size_t)7;
+    if (!take) break;
+    memcpy(out + i, (const uint8_t*)h->s + h->pos, take);
+    i += take;
+    h->pos += take;
+  }
+#endif
+  for (; i < len; i++) {
     if (h->pos == FO_RATE) { keccak_f1600(h->s); h->pos = 0; }
     out[i] = (uint8_t)(h->s[h->pos >> 3] >> (8 * (h->pos & 7)));
     h->pos++;

@@ -56,8 +56,8 @@ def _p(a, t=ctypes.c_uint8):
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = lib = _build("oracle", "libfalcon_oracle.so")
+    def __init__(self, lib=None):
+        self.lib = lib = lib if lib is not None else _build("oracle", "libfalcon_oracle.so")
         lib.fo_debug_size.restype = ctypes.c_size_t
         assert lib.fo_debug_size() == ctypes.sizeof(OracleDebug) == _DBG_DTYPE.itemsize
         lib.fo_verify.argtypes = [ctypes.c_uint, _u8p, _u8p, ctypes.c_size_t, _u8p, ctypes.c_void_p]
@@ -351,6 +351,28 @@ def oracle():
     if _oracle is None:
         _oracle = Oracle()
     return _oracle
+
+
+_oracle_native = None
+
+
+def oracle_native():
+    """The TIMED build of the oracle (oracle/Makefile target `native`: -O3 -march=native -DFO_NATIVE), compiled on the
+    machine that runs it; None where that is not possible (no compiler). bench.py's cpu_baseline times this one; the
+    checker everywhere else is oracle()."""
+    global _oracle_native
+    if _oracle_native is None:
+        import fcntl
+        path = os.path.join(ROOT, "oracle", "_native", "libfalcon_oracle_native.so")
+        try:
+            with open(os.path.join(ROOT, "oracle", ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                                      stderr=subprocess.DEVNULL)
+            _oracle_native = Oracle(ctypes.CDLL(path))
+        except (OSError, subprocess.CalledProcessError):
+            return None
+    return _oracle_native
 
 
 def corpus():
