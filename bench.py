@@ -14,14 +14,24 @@ With --gpus N > 1 every rank verifies its own shard (independent items, no colle
 scaling); rank 0 prints ONE JSON line.
 
 Extra legs on rank 0 at N == 1 (outside the timed region): cpu_baseline (the CPU oracle, a port of the reference's
-falcon::verify<N>, over a bounded sample of the same corpus with pthreads, plus an item-by-item comparison of the accept
-flags with the GPU's) and `extras` (the other BASELINE configs, the prepared-key path against the packed path in
-interleaved rounds, the host-buffer entry points).
+falcon::verify<N>, built on this machine with -O3 -march=native, over a bounded sample of the same corpus with pthreads,
+plus an item-by-item comparison of the accept flags with the GPU's) and `extras` (the other BASELINE configs, the
+prepared-key path against the packed path in interleaved rounds, the host-buffer entry points, resident key sets).
+Before anything touches the GPU, rank 0 at N == 1 also runs ONE rocprofv3 counter pass over the same launch shape in a
+child process (GRBM_GUI_ACTIVE, SQ_INSTS_VALU): the clock the chip holds under these kernels and the instructions they
+issue, quoted in `roofline.pmc` as of this run (--no-pmc skips it; profiles/hbm_traffic.json is the fallback).
+At N > 1 every rank additionally times BASELINE config 5's shape (mixed Falcon-512 + Falcon-1024, 2^23 items per rank)
+after the headline region: `extras.mixed_512_1024_config5`.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -37,17 +47,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # chi 50, iota 2) and an item needs 8.593 permutations on average (the kernel runs 9 for every item);
 # signature decoding 10 per coefficient. By construction these are <= what the kernels issue, so achieved / peak <= 1.
 # REF_OPS is SURVEY.md 8(d)'s model of the REFERENCE's work (11 per butterfly, 4 transforms), reported beside it only.
+# Round 3: a butterfly is 4 (two-instruction Plantard product, add, subtract); the inverse transform's first stage
+# multiplies nothing (2 per butterfly) and its last step is one product per coefficient.
+def _verify_ops(n, logn, draws):
+    bf = n // 2 * logn                     # butterflies per transform
+    return 2 * bf * 4 + ((bf - n // 2) * 4 + n // 2 * 2 + n * 2) + n * 5 + n * 2 + n * 6 + draws * 3
+
+
 ALG_OPS = {
-    9: {"verify_kernel": 3 * 2304 * 5 + 512 * 5 + 512 * 2 + 512 * 6 + 612 * 3,
+    9: {"verify_kernel": _verify_ops(512, 9, 612),
         "hash_kernel": 8.593 * 24 * 180,
         "decode_kernel": 512 * 10},
-    10: {"verify_kernel": 3 * 5120 * 5 + 1024 * 5 + 1024 * 2 + 1024 * 6 + 1224 * 3,
+    10: {"verify_kernel": _verify_ops(1024, 10, 1224),
          "hash_kernel": 16.7 * 24 * 180,
          "decode_kernel": 1024 * 10},
 }
+ALG_OPS_R02_VERIFY = {9: 3 * 2304 * 5 + 512 * 5 + 512 * 2 + 512 * 6 + 612 * 3,   # the work model of round 2 (5 per butterfly), kept
+                      10: 3 * 5120 * 5 + 1024 * 5 + 1024 * 2 + 1024 * 6 + 1224 * 3}   # so that the rounds' fractions can be compared
 REF_OPS_512 = {"hash_kernel": 8.593 * 7440, "verify_kernel": 9216 * 11 + 1024 * 5 + 546 * 4 + 512 * 3 + 512 * 3,
                "decode_kernel": 512 * 10}
-POLYMUL_OPS_512 = 3 * 2304 * 5 + 512 * 9 + 512 * 2   # transforms, pointwise (two reductions + product), final reduction
+POLYMUL_OPS_512 = 2 * 2304 * 4 + (2048 * 4 + 256 * 2 + 512 * 2) + 512 * 5   # transforms, pointwise (reduction + product)
 BYTES = {9: 897 + 666 + 32 + 1, 10: 1793 + 1280 + 32 + 1}   # compulsory HBM bytes per verify
 PEAK_VALU_TIOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (full-rate instructions)
 PEAK_HBM_GBS = 8000.0
@@ -75,6 +94,53 @@ def host_cores():
     return n, src
 
 
+def pmc_child_pass(items, steps=3):
+    """One rocprofv3 counter pass over the headline launch shape (tools/prof_run.py: `steps` device-resident calls of
+    2^20 Falcon-512 items) in a child process, started before this process touches the GPU. Returns per kernel the
+    clock (GRBM_GUI_ACTIVE, summed over the 8 XCDs, / 8 / the dispatch's own duration) and the issued vector
+    instructions (SQ_INSTS_VALU), medians over the dispatches; None when the profiler is not there or the pass fails."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = tempfile.mkdtemp(prefix="fa_pmc_")
+    try:
+        t0 = time.time()
+        r = subprocess.run([exe, "--pmc", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "prof_run.py"), "9", str(items), str(steps)],
+                           cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            log("pmc pass failed:", r.stderr[-400:])
+            return None
+        rows = {}
+        for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                name = row["Kernel_Name"]
+                if "fa::" not in name:
+                    continue
+                short = ("decode_kernel" if "decode_fast_kernel" in name else "hash_kernel" if "hash_kernel" in name
+                         else "verify_kernel" if "verify_kernel" in name else None)
+                if short is None:
+                    continue
+                d = rows.setdefault((short, row["Dispatch_Id"]), {})
+                d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                d["ns"] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        res = {}
+        for (short, _), d in rows.items():
+            if d.get("ns", 0) > 0 and "GRBM_GUI_ACTIVE" in d:
+                e = res.setdefault(short, {"clock": [], "valu": [], "ns": []})
+                e["clock"].append(d["GRBM_GUI_ACTIVE"] / 8 / d["ns"])
+                e["valu"].append(d.get("SQ_INSTS_VALU", 0.0))
+                e["ns"].append(d["ns"])
+        med = lambda v: sorted(v)[len(v) // 2]
+        return {k: {"clock_ghz": med(v["clock"]), "valu_instructions": med(v["valu"]), "dispatch_ms_under_profiler": med(v["ns"]) / 1e6,
+                    "dispatches": len(v["clock"])} for k, v in res.items()} | {"_seconds": time.time() - t0}
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        log("pmc pass failed:", repr(e))
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,18 +160,28 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter pass that precedes the run at N == 1")
+    ap.add_argument("--mixed-steps", type=int, default=3, help="timed steps of the config-5 leg at N > 1")
+    ap.add_argument("--mixed-items", type=int, default=1 << 23, help="items per rank of the config-5 leg at N > 1")
     args = ap.parse_args()
     workload = args.workload or ("falcon512" if args.logn == 9 else "falcon1024")
     mixed = workload == "mixed"
     logn = 10 if workload == "falcon1024" else 9
     malformed = args.malformed if args.malformed >= 0 else (250 if workload == "falcon1024" and args.workload else 0)
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    pmc_now = None
+    if world == 1 and not args.no_pmc and workload == "falcon512" and (args.items or (1 << 20)) == 1 << 20 and not os.environ.get("ROCPROFILER_CONFIGURED") \
+            and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
+        pmc_now = pmc_child_pass(1 << 20)   # before `import torch`: nothing in this process has touched the GPU yet
+        if pmc_now:
+            log(f"[rank 0] counter pass in {pmc_now['_seconds']:.0f}s:", {k: v for k, v in pmc_now.items() if k != "_seconds"})
+
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if args.same_gpu:
@@ -264,10 +340,15 @@ def main():
             "avg_launch_ms": avg_ms, "launches_timed": kern_n[dom], "items_per_launch": items_per_launch,
             "algorithmic_ops_per_item": ops_item,
             "note": "integer VALU work, no MFMA. achieved = minimum lane-operations of this kernel's work at the issued cost (bench.py "
-                    "ALG_OPS: 5 per butterfly, 3 transforms; 180 per Keccak round) x items per launch / average launch time measured with "
+                    "ALG_OPS: 4 per butterfly, 3 transforms; 180 per Keccak round) x items per launch / average launch time measured with "
                     "HIP events in this run; peak = 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s, which only full-rate instructions reach "
-                    "(multiplies, mad, bitop3, alignbit issue at half rate: DESIGN.md section 6)",
+                    "(every instruction of these streams takes a four-cycle issue slot: DESIGN.md section 6). Round 3 removed a sixth "
+                    "of the verify kernel's work (4 instead of 5 instructions per butterfly), so this fraction is not comparable with "
+                    "round 2's: frac_round2_work_model is",
         }
+        if dom == "verify_kernel" and not mixed:
+            r2 = ALG_OPS_R02_VERIFY[logn] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roof["frac_round2_work_model"] = r2 / PEAK_VALU_TIOPS
         if workload == "falcon512":
             roof["reference_op_model"] = {"ops_per_item": REF_OPS_512[dom],
                                           "rate_Tiops": REF_OPS_512[dom] * items_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
@@ -288,13 +369,20 @@ def main():
             try:   # counters of the same launch (2^20 Falcon-512 items), collected in separate rocprofv3 --pmc passes
                 counters = json.load(open(tpath))
                 roof["traffic"] = counters["hbm_bytes_per_launch"][dom]
+                roof["traffic_source"] = PMC_SOURCE + " (" + counters.get("_from", "?") + "): HBM bytes do not depend on the clock"
                 issued = counters["valu_instructions_per_launch"][dom]
                 clock = counters.get("clock_ghz", {}).get(dom)
-                roof["pmc"] = {"source": PMC_SOURCE + " (" + counters.get("_from", "?") + ")",
+                source = PMC_SOURCE + " (" + counters.get("_from", "?") + ")"
+                if pmc_now and dom in pmc_now:   # this run's own counter pass (pmc_child_pass) takes precedence
+                    issued, clock = pmc_now[dom]["valu_instructions"] or issued, pmc_now[dom]["clock_ghz"]
+                    source = ("this run: rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU over tools/prof_run.py (3 launches of the same "
+                              "2^20 items) in a child process on this GPU, before the timed region")
+                roof["pmc"] = {"source": source,
                                "issued_valu_wave_instructions": issued,
                                "issued_lane_ops_frac_of_peak": issued * 64 / (avg_ms * 1e-3) / 1e12 / PEAK_VALU_TIOPS,
                                "clock_ghz_from_GRBM_GUI_ACTIVE": clock,
-                               "cycles_per_valu_instruction_per_simd": (clock * 1e9 * avg_ms * 1e-3 * 1024 / issued) if clock else None}
+                               "cycles_per_valu_instruction_per_simd": (clock * 1e9 * avg_ms * 1e-3 * 1024 / issued) if clock else None,
+                               "all_kernels": {k: v for k, v in pmc_now.items() if k != "_seconds"} if pmc_now else None}
             except Exception as e:   # the profile is optional
                 log("no PMC summary:", e)
         result["roofline"] = roof
@@ -345,27 +433,52 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu and not mixed:
         # ---- CPU baseline: the oracle over a bounded sample of the same corpus ----
         ns = min(args.cpu_sample, n_items)
-        orc = support.oracle()
+        orc = support.oracle()   # the checker: portable build
+        fast = support.oracle_native()   # the timed build: this machine's -O3 -march=native (oracle/Makefile `native`), the reference's own flags
+        timed, build = (fast, fast.built_with + ", built on this machine") if fast else (orc, "gcc -O3 -std=c11 (no native build here)")
+        timed.verify_many(logn, pk[:4096], msg[:4096], sig[:4096], threads=threads)   # page in
         t0 = time.perf_counter()
-        flags, _ = orc.verify_many(logn, pk[:ns], msg[:ns], sig[:ns], threads=threads)
+        tflags, _ = timed.verify_many(logn, pk[:ns], msg[:ns], sig[:ns], threads=threads)
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
-        n1 = min(8192, ns)
-        orc.verify_many(logn, pk[:n1], msg[:n1], sig[:n1], threads=1)
+        n1 = min(16384, ns)
+        timed.verify_many(logn, pk[:n1], msg[:n1], sig[:n1], threads=1)
         dt1 = time.perf_counter() - t1
-        # every accept flag of the timed corpus against the CPU result: the rest of the items, untimed
-        if ns < n_items:
-            rest, _ = orc.verify_many(logn, pk[ns:], msg[ns:], sig[ns:], threads=threads)
-            flags = np.concatenate([flags, rest])
+        # where one verify's time goes on this host (the timed build's own entry points, 3,000 calls each through ctypes,
+        # about a microsecond of call overhead included): the reference runs 3 ntt + 1 intt per verify (verification.hpp:47-57)
+        import ctypes
+        prof_us = {}
+        u8p, u16p, i32p = (ctypes.POINTER(t) for t in (ctypes.c_uint8, ctypes.c_uint16, ctypes.c_int32))
+        poly = np.arange(1 << logn, dtype=np.uint16)
+        c_out = np.zeros(1 << logn, np.uint16)
+        s2_out = np.zeros(1 << logn, np.int32)
+        sig0, pk0, salt0, msg0 = (np.ascontiguousarray(a) for a in (sig[0], pk[0], sig[0][1:41], msg[0]))
+        legs = {"ntt": lambda: timed.lib.fo_ntt(poly.ctypes.data_as(u16p), logn),
+                "intt": lambda: timed.lib.fo_intt(poly.ctypes.data_as(u16p), logn),
+                "hash_to_point": lambda: timed.lib.fo_hash_to_point(logn, salt0.ctypes.data_as(u8p), 40, msg0.ctypes.data_as(u8p), 32,
+                                                                     c_out.ctypes.data_as(u16p)),
+                "decompress_sig": lambda: timed.lib.fo_decompress_sig(logn, sig0.ctypes.data_as(u8p), s2_out.ctypes.data_as(i32p)),
+                "decode_pkey": lambda: timed.lib.fo_decode_pkey(logn, pk0.ctypes.data_as(u8p), c_out.ctypes.data_as(u16p))}
+        for name, fn in legs.items():
+            fn()
+            tl = time.perf_counter()
+            for _ in range(3000):
+                fn()
+            prof_us[name] = (time.perf_counter() - tl) / 3000 * 1e6
+        # every accept flag of the timed corpus against the CPU checker, untimed; the timed build's flags
+        # against the checker's on the sample
+        flags, _ = orc.verify_many(logn, pk, msg, sig, threads=threads)
         gpu_flags = d_acc.cpu().numpy()
         result["cpu_baseline"] = {
             "value": ns / dt, "unit": "verifies/s", "cores": threads, "kind": "port",
             "sample": f"first {ns} items of the same corpus, one verify per item, {threads} pthreads = {threads_src} "
-                      f"(machine: {os.cpu_count()} CPUs; ~{dt * threads:.0f} core-seconds; oracle/falcon_oracle.c, gcc -O3 -std=c11); "
-                      f"single thread: {1e6 * dt1 / n1:.1f} us/verify",
-            "host_cpus": os.cpu_count(), "single_thread_us": 1e6 * dt1 / n1,
+                      f"(machine: {os.cpu_count()} CPUs; ~{dt * threads:.0f} core-seconds; oracle/falcon_oracle.c, {build}); "
+                      f"single thread: {1e6 * dt1 / n1:.1f} us/verify (the reference publishes 19.8 us on an i7-1260P, README.md:150-155)",
+            "host_cpus": os.cpu_count(), "single_thread_us": 1e6 * dt1 / n1, "build": build,
+            "single_thread_profile_us": prof_us,
             "accept_flags_compared": int(flags.size),
             "accept_mismatches_vs_gpu": int((gpu_flags != (flags & 1)).sum()),
+            "timed_build_mismatches_vs_checker": int((tflags != flags[:ns]).sum()),
         }
     elif rank == 0 and world == 1 and not args.no_cpu and mixed:
         # mixed workload: the oracle over a bounded sample of the first pairs (both classes), flags compared item by item
@@ -454,6 +567,26 @@ def main():
         extras["host_buffers_pinned_pcie_inclusive"] = {"verifies_per_s": nh / dt, "items": nh,
                                                         "input_GBps": nh * (pk.shape[1] + sig.shape[1] + 32) / dt / 1e9,
                                                         "accepted_fraction": float(pin[3].array.mean())}
+        # resident key set (fa_keyset_create / fa_verify_many_keyset): the keys stay on the GPU in prepared form, a call
+        # sends signatures, messages and 4-byte key indices only -- 702 instead of 1,595 bytes per item over the host link
+        ks = ctx.keyset_create(logn, pk=pk[:nh])
+        kidx_pin = capi.PinnedArray((nh,), dtype=np.uint32)
+        kidx_pin.array[...] = np.arange(nh, dtype=np.uint32)
+        for name, (m_a, s_a, k_a, a_out) in (("pageable", (msg[:nh], sig[:nh], np.arange(nh, dtype=np.uint32), None)),
+                                            ("pinned", (pin[1].array, pin[2].array, kidx_pin.array, pin[3].array))):
+            ctx.verify_many_keyset(ks, m_a, s_a, key_idx=k_a, accept_out=a_out)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                k_acc = ctx.verify_many_keyset(ks, m_a, s_a, key_idx=k_a, accept_out=a_out)
+                ts.append(time.perf_counter() - t0)
+            dt = sorted(ts)[1]
+            extras["host_buffers_resident_keys" + ("" if name == "pinned" else "_pageable")] = {
+                "verifies_per_s": nh / dt, "items": nh, "caller_memory": name, "input_bytes_per_item": sig.shape[1] + 32 + 4,
+                "input_GBps": nh * (sig.shape[1] + 32 + 4) / dt / 1e9, "keys_resident": nh,
+                "accept_mismatches_vs_device_path": int((k_acc != d_acc[:nh].cpu().numpy()).sum())}
+        ks.close()
+        kidx_pin.close()
         for b in pin:
             b.close()
         # decoded-key fast path: keys prepared once (NTT(h) resident), same 2^20 Falcon-512 items, against the
@@ -533,6 +666,55 @@ def main():
                                            "note": "mean of 200 device-resident calls, median of 200 host-buffer calls"}
         extras["one_item_per_call_latency"] = lat
         result["extras"] = extras
+
+    if world > 1 and not args.no_extras and workload == "falcon512" and n_items >= 1 << 15:
+        # BASELINE config 5 on the driver's plain multi-GPU command: after the headline region every rank builds ITS share
+        # of the mixed batch -- 2^23 items, 50/50 Falcon-512 / Falcon-1024 (the latter with the 25 % malformed mix), tiled
+        # on the device from this rank's two 2^20-item corpora -- and all ranks time the same number of steps between two
+        # barriers. Items are independent: no collective on the data path, the only way this fails to scale is a
+        # straggler, so the per-rank rates are reported too.
+        t0 = time.time()
+        pk2, msg2, sig2, _ = support.corpus().generate(10, n_items, seed=0xFA1C1024, first=rank * n_items, mlen=32, malformed_permille=250,
+                                                        threads=threads)
+        e_dev = upload(pk2, msg2, sig2)
+        mx, _ = build_mixed([d_pk, d_msg, d_sig], e_dev, args.mixed_items, 0x5EED + rank)
+        del e_dev
+        torch.cuda.empty_cache()
+        t_build = time.time() - t0
+        run_mixed(mx)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.mixed_steps):
+            run_mixed(mx)
+        torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0
+        dist.barrier()
+        t_all = time.perf_counter() - t0
+        # this rank's accept bytes against what each item's class dictates: the single-class result of the headline corpus
+        # for the Falcon-512 items (all valid), a sample of the Falcon-1024 items against the oracle
+        tags = mx["logn"][:1 << 15].cpu().numpy()
+        got = mx["accept"][:1 << 15].cpu().numpy()
+        src = np.repeat(np.arange(1 << 14), 2)
+        o10, _ = support.oracle().verify_many(10, pk2[:1 << 14], msg2[:1 << 14], sig2[:1 << 14], threads=threads)
+        want = np.where(tags == 9, d_acc[:1 << 14].cpu().numpy()[src], (o10 & 1)[src])
+        vals = torch.tensor([t_all, t_own, t_build, float((got != want).sum()), float(mx["count"])], dtype=torch.float64, device=red_dev)
+        gathered = [torch.zeros_like(vals) for _ in range(world)]
+        dist.all_gather(gathered, vals)
+        if rank == 0:
+            g = np.stack([x.cpu().numpy() for x in gathered])
+            items_total = int(g[:, 4].sum())
+            per_rank = g[:, 4] * args.mixed_steps / g[:, 1]
+            result.setdefault("extras", {})["mixed_512_1024_config5"] = {
+                "verifies_per_s": items_total * args.mixed_steps / float(g[:, 0].max()), "items_total": items_total, "items_per_rank": int(g[0, 4]),
+                "steps": args.mixed_steps, "share_1024": 0.5, "per_rank_verifies_per_s_min": float(per_rank.min()),
+                "per_rank_verifies_per_s_max": float(per_rank.max()), "per_rank_corpus_build_s_max": float(g[:, 2].max()),
+                "accept_mismatches_first_32768_per_rank_sum": int(g[:, 3].sum()),
+                "note": "BASELINE.json configs[4]: mixed Falcon-512 + Falcon-1024 batch sharded by item over the ranks, no collective on the "
+                        "data path; timed between two barriers, aggregate = all items / the slowest rank's time"}
+        del mx
+        torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -3,12 +3,14 @@
 Every (public key, message, signature) triple is independent, so a batch of `count` items is cut
 into `world` contiguous ranges of ceil(count / world) items, one per rank / GPU, and nothing is
 exchanged on the data path. The only step that crosses ranks is the host-side gather of the
-per-item accept bytes, done here with torch.distributed on CPU tensors (gloo) or, when the
-process group is RCCL-only, on device tensors.
+per-item accept bytes, done here with torch.distributed on CPU tensors over gloo (an RCCL-only
+process group gets a gloo companion for it): no collective touches the GPUs or xGMI.
 
 The same split is used by falcon::verify_many_sharded<N> in include/falcon_amd.hpp.
 """
 import numpy as np
+
+_CPU_GROUPS = {}   # process group -> its gloo companion (gather_accept)
 
 
 def shard_range(count, world, rank):
@@ -47,18 +49,26 @@ def gather_accept(local_accept, count, dst=0, group=None):
     if local_accept.shape[0] != hi - lo:
         raise ValueError(f"rank {rank}: shard holds {local_accept.shape[0]} items, expected {hi - lo}")
     per = -(-count // world)
-    on_gpu = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    buf = torch.zeros(max(per, 1), dtype=torch.uint8, device=dev)   # equal-sized pieces for all_gather
-    buf[:hi - lo] = torch.from_numpy(local_accept).to(dev)
+    # A HOST-side gather (BASELINE.json north_star: "only a host-side gather of per-signature accept bitmaps remains"): CPU
+    # tensors over gloo. A process group that is RCCL-only gets a gloo companion over the same ranks, made once (every rank
+    # comes through here, so the collective new_group call is matched); nothing crosses xGMI.
+    cpu_group = group
+    if dist.get_backend(group) == "nccl":
+        key = id(group) if group is not None else None
+        if key not in _CPU_GROUPS:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            _CPU_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+        cpu_group = _CPU_GROUPS[key]
+    buf = torch.zeros(max(per, 1), dtype=torch.uint8)   # equal-sized pieces for all_gather
+    buf[:hi - lo] = torch.from_numpy(local_accept)
     pieces = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(pieces, buf, group=group)
+    dist.all_gather(pieces, buf, group=cpu_group)
     if rank != dst:
         return None
     out = np.empty(count, np.uint8)
     for r in range(world):
         a, b = shard_range(count, world, r)
-        out[a:b] = pieces[r][:b - a].cpu().numpy()
+        out[a:b] = pieces[r][:b - a].numpy()
     return out
 
 

@@ -66,9 +66,14 @@ def test_two_ranks_one_gpu_sharded_verify(tmp_path, oracle, corpus, count):
 
 def test_bench_two_rank_rehearsal():
     """bench.py as the driver launches it for N = 2, with both ranks on GPU 0 and gloo for the barrier."""
-    r = _launch(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--items", "65536", "--backend", "gloo", "--same-gpu"])
+    r = _launch(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--items", "65536", "--backend", "gloo", "--same-gpu",
+                 "--mixed-items", "262144", "--mixed-steps", "2"])
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["accepted_fraction"] == 1.0
     assert d["value"] > 0 and d["roofline"]["frac"] <= 1.0
+    # the plain multi-GPU command also measures BASELINE config 5's shape (mixed 512 + 1024) on every rank
+    m = d["extras"]["mixed_512_1024_config5"]
+    assert m["items_total"] == 2 * 262144 and m["items_per_rank"] == 262144 and m["accept_mismatches_first_32768_per_rank_sum"] == 0
+    assert 0 < m["per_rank_verifies_per_s_min"] <= m["per_rank_verifies_per_s_max"] and m["verifies_per_s"] > 0

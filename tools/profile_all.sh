@@ -6,7 +6,7 @@ tag="${1:-r01}"
 out="gpurun_out/prof_$tag"
 mkdir -p "$out"
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu --no-pmc \
   > "$out/bench_under_rocprof.json" 2> "$out/stats.log" || { echo "stats run failed"; tail -5 "$out/stats.log"; exit 1; }
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY" \
