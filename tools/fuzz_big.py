@@ -17,14 +17,15 @@ orc = support.oracle()
 out = {}
 for logn, total in ((9, n9), (10, n10)):
     bad = {"accept_exact": 0, "accept_wrap32": 0, "status": 0, "norm_exact": 0, "norm_wrap32": 0, "accept_async_dev": 0,
-           "accept_noalloc": 0, "accept_prepared": 0, "accept_small_calls": 0, "status_small_calls": 0, "norm_small_calls": 0}
+           "accept_noalloc": 0, "accept_prepared": 0, "accept_small_calls": 0, "status_small_calls": 0, "norm_small_calls": 0,
+           "accept_keyset": 0, "accept_keyset_indexed": 0, "ntt_elements": 0, "intt_elements": 0, "polymul_elements": 0}
     done = 0
     classes = {}
     t0 = time.time()
     step = 1 << 19
     for first in range(0, total, step):
         n = min(step, total - first)
-        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0223 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
+        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0323 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
         flags, odbg = orc.verify_many(logn, pk, msg, sig, debug=True, threads=16)
         acc, gdbg = ctx.verify_many(logn, pk, msg, sig, debug=True)
         accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)
@@ -59,6 +60,27 @@ for logn, total in ((9, n9), (10, n10)):
         torch.cuda.synchronize()
         bad["accept_prepared"] += int((d_acc.cpu().numpy() != (flags & 1)).sum())
         del t, d_acc, d_prep
+        # round 3: the same items against their keys resident on the GPU (fa_keyset), host buffers; then 61 keys shared by
+        # all items through an index (most then fail the norm: checked against the oracle with the keys permuted likewise)
+        ks = ctx.keyset_create(logn, pk=pk)
+        bad["accept_keyset"] += int((ctx.verify_many_keyset(ks, msg, sig) != (flags & 1)).sum())
+        ks.close()
+        m = min(n, 1 << 17)
+        kidx = (np.arange(m) % 61).astype(np.uint32)
+        ks = ctx.keyset_create(logn, pk=pk[:61])
+        want_idx, _ = orc.verify_many(logn, pk[kidx], msg[:m], sig[:m], threads=16)
+        bad["accept_keyset_indexed"] += int((ctx.verify_many_keyset(ks, msg[:m], sig[:m], key_idx=kidx) != (want_idx & 1)).sum())
+        ks.close()
+        # the transforms as operators (ntt.hpp:120-200) and the product built from them, element for element, on the decoded
+        # keys of the first 4096 items (raw 14-bit fields, values >= q included)
+        h = np.stack([orc.decode_pkey(logn, k)[1] for k in pk[:4096]])
+        fwd = ctx.ntt_many(logn, h)
+        want_fwd = np.stack([orc.ntt(r % 12289, logn) for r in h])
+        bad["ntt_elements"] += int((fwd != want_fwd).sum())
+        bad["intt_elements"] += int((ctx.ntt_many(logn, fwd, inverse=True) != h % 12289).sum())
+        prod = ctx.polymul_many(logn, h[:2048], h[2048:])
+        want_prod = np.stack([orc.polymul(a, b, logn) for a, b in zip(h[:256], h[2048:2304])])
+        bad["polymul_elements"] += int((prod[:256] != want_prod).sum())
         # the first 2^15 items again in calls of a few items to a few thousand: the one-wave-per-item front (<= 512), its
         # copy-free host path, the lane-pair sponge (<= 2^14)
         sizes, c0, k = (1, 2, 3, 5, 17, 64, 65, 100, 333, 512, 513, 1000, 4096), 0, 0
