@@ -318,8 +318,10 @@ __device__ __forceinline__ void ntt_forward2(uint32_t (&x)[Geo<LOGN>::R], uint32
 }
 
 // x: <= q, phase-C layout (bit-reversed order)  ->  coefficients in phase-A layout (natural order), canonical,
-// the 1/N of ntt.hpp:193-199 included in the final scaling.
-template <int LOGN>
+// the 1/N of ntt.hpp:193-199 included in the final scaling. SCALE = false leaves the final scaling to the caller:
+// x[m] is then lazy (below (2 logn + 1) q) and still to be multiplied by T.sc[m << 6] (the verify kernel's epilogue
+// does that inside the reduction it needs anyway).
+template <int LOGN, bool SCALE = true>
 __device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const TwTabs& T, uint32_t* __restrict__ buf,
                                             uint32_t lane)
 {
@@ -331,6 +333,7 @@ __device__ __forceinline__ void ntt_inverse(uint32_t (&x)[Geo<LOGN>::R], const T
   bfly_stages<LOGN, false, G::LB, G::PB, 0, TW_PHASE_B, false>(x, T.iB, 0u);
   transpose<LOGN, 3>(x, buf, lane);
   bfly_stages<LOGN, false, G::LB, 6, 0, TW_PHASE_A, false>(x, T.iA, 0u);
+  if constexpr (!SCALE) return;
   valu_fence();
 #pragma unroll
   for (int m = 0; m < R; m++) x[m] = plant_lo<false>(x[m], T.sc[m << 6]);
@@ -428,9 +431,10 @@ __device__ __forceinline__ void unpack_pkey(const uint32_t (&pkw)[Geo<LOGN>::PKD
     y[m] = __builtin_amdgcn_alignbit(src[28 * m + 1], src[28 * m], sh) & 0x3fffu;  // <= 16383, reduced by the transform itself
 }
 
-// Prepared keys: NTT(h) of a public key times -2^32 (the factor the verify kernel's two-variable Plantard product
-// divides by, zq.hpp plant2), canonical u16, in the order the verify kernel consumes it (lane L holds positions
-// L*R .. L*R+R-1 of the transform's bit-reversed output): an opaque blob. One wave per key.
+// Prepared keys: NTT(h) of a public key times +2^32, canonical u16, in the order the verify kernel consumes it (lane L
+// holds positions L*R .. L*R+R-1 of the transform's bit-reversed output): an opaque blob. One wave per key. The factor:
+// the verify kernel's two-variable Plantard product (zq.hpp plant2) yields -a*b*2^-32, so with it the product comes out
+// as MINUS NTT(s2)*NTT(h) -- which is what the epilogue wants (s1 = c + (-s2*h) is a sum of non-negative values).
 // PACKED: input rows are encoded keys (decode_pkey, decoding.hpp:18-48; a wrong header yields the
 // PREPARED_BAD_KEY mark, the counterpart of falcon.hpp:240-243); else rows are decoded polynomials h as
 // verification::verify takes them (N u16, any value: the ff_t arithmetic reduces, ff.hpp:69-76).
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(VERIFY_WG) void prepare_keys_kernel(const uint8_t* 
     uint32_t* out = (uint32_t*)(prepared + (size_t)key * N) + lane * (R / 2);
 #pragma unroll
     for (int j = 0; j < R / 2; j++) {
-      uint32_t lo = plant(y[2 * j], W_NEG_R), hi = plant(y[2 * j + 1], W_NEG_R);
+      uint32_t lo = plant(y[2 * j], W_POS_R), hi = plant(y[2 * j + 1], W_POS_R);
       if (!ok) lo = hi = 0u;
       if (!ok && j == 0 && lane == 0) lo = PREPARED_BAD_KEY;
       out[j] = lo | (hi << 16);
@@ -681,9 +685,9 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       if constexpr (PREPARED) {
         ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
-        for (int m = 0; m < R; m++) {  // -2^32 NTT(h), canonical, already in this lane's phase-C positions
+        for (int m = 0; m < R; m++) {  // 2^32 NTT(h), canonical, already in this lane's phase-C positions
           const uint32_t hv = (hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
-          x[m] = plant2(x[m], hv);  // polynomial.hpp:99-110; x < 2^16 + 2 logn q, hv < q: the product is below 2^32
+          x[m] = plant2(x[m], hv);  // MINUS the product of polynomial.hpp:99-110; x < 2^16 + 2 logn q, hv < q: below 2^32
         }
       } else {
         // One transform after the other: interleaving them (ntt_forward2) costs Falcon-1024 its third wave per SIMD
@@ -691,28 +695,51 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         ntt_forward<LOGN>(y, T, buf, lane);
         ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
-        for (int m = 0; m < R; m++) x[m] = plant(x[m], W_NEG_R);  // canonical, times -2^32
+        for (int m = 0; m < R; m++) x[m] = plant(x[m], W_POS_R);  // canonical, times 2^32
 #pragma unroll
-        for (int m = 0; m < R; m++) x[m] = plant2(x[m], y[m]);    // polynomial.hpp:99-110; y < 16384 + 2 logn q
+        for (int m = 0; m < R; m++) x[m] = plant2(x[m], y[m]);    // MINUS the product of polynomial.hpp:99-110; y < 16384 + 2 logn q
       }
-      ntt_inverse<LOGN>(x, T, buf, lane);  // x = s2*h, natural order, phase-A layout, canonical
+      ntt_inverse<LOGN, false>(x, T, buf, lane);  // sc[i] * x = -s2*h mod q, natural order, phase-A layout; x lazy
 
       // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
+      // s1 = craw + sc*x (mod q), a sum of non-negative values. The centred value v lies in [half - q, half - 1]
+      // (verification.hpp:59-68: values >= half = 6144 go negative; the specification's centring has half = 6145), so
+      // v + (q - half) is the canonical residue of u = craw + (q - half) + sc*x -- and that is ONE Plantard reduction:
+      // the low products are linear, low(x * W_sc) + low(u0 * W_one) is the low product of the sum, and the high product
+      // by q reduces it (zq.hpp; exact because x * q + u0 * 1337 < 258,069 q + 79,878 * 1337 < 2^32). Per coefficient:
+      // low product, add, multiply-add, high product, subtract, multiply-add -- no comparison, no select, and the
+      // inverse transform's final scaling costs nothing of its own.
       uint32_t acc = 0;
+      const uint32_t shift = Q - A.half;
+      static_assert((2ull * LOGN + 1ull) * Q * (Q - 1ull) + (61444ull + Q) * NEG_R < (1ull << 32), "fused scaling and reduction");
 #pragma unroll
-      for (int m = 0; m < R; m++) {
-        const uint32_t i = idxA<LOGN>(lane, m);
-        const uint32_t craw = cbuf[i];                              // < 61445
-        const uint32_t r0 = (uint32_t)reduce((int32_t)craw - (int32_t)x[m]); // s1 in [0, q] (x[m] in [0, q))
-        const uint32_t mag = r0 >= A.half ? Q - r0 : r0;            // |centred s1|, verification.hpp:59-68 (q -> 0)
-        acc += mul24(mag, mag);
-        const uint32_t r = DEBUG ? csub(r0, Q) : r0;                // canonical s1, debug output only
-        if (DEBUG) {
-          if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw);
-          if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)(r >= A.half ? (int32_t)r - (int32_t)Q : (int32_t)r);
-          if (A.dbg.s2) {
-            const uint32_t v = s2keep[m];
-            A.dbg.s2[(size_t)item * N + i] = (int16_t)(v > Q / 2u ? (int32_t)v - (int32_t)Q : (int32_t)v);
+      for (int m0 = 0; m0 < R; m0 += 8) {  // eight at a time: Falcon-1024's sixteen would cost its fourth wave per SIMD
+        uint32_t craw[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) craw[k] = cbuf[idxA<LOGN>(lane, m0 + k)];  // < 61445
+        valu_fence();
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = plant_lo<false>(x[m0 + k], T.sc[(m0 + k) << 6]);
+        valu_fence();
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] += __umul24(craw[k] + shift, W_ONE);
+        valu_fence();
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = plant_hi(w[k]);                     // v + (q - half), in [0, q)
+        valu_fence();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int m = m0 + k;
+          const uint32_t i = idxA<LOGN>(lane, m);
+          const int32_t v = (int32_t)w[k] - (int32_t)shift;                    // centred s1
+          acc += (uint32_t)__mul24(v, v);                                      // |v| <= 6145
+          if (DEBUG) {
+            if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw[k]);
+            if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)v;
+            if (A.dbg.s2) {
+              const uint32_t sv = s2keep[m];
+              A.dbg.s2[(size_t)item * N + i] = (int16_t)(sv > Q / 2u ? (int32_t)sv - (int32_t)Q : (int32_t)sv);
+            }
           }
         }
       }

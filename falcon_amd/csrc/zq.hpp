@@ -42,6 +42,8 @@ __host__ __device__ constexpr uint32_t plant_const(uint32_t w)
 constexpr uint32_t W_ONE = plant_const(1u);                               // plant(a, W_ONE) = a mod q
 constexpr uint32_t NEG_R = (Q - (uint32_t)((1ull << 32) % Q)) % Q;        // -2^32 mod q
 constexpr uint32_t W_NEG_R = plant_const(NEG_R);                          // plant(a, W_NEG_R) = -a * 2^32 mod q
+constexpr uint32_t POS_R = (uint32_t)((1ull << 32) % Q);                  // 2^32 mod q
+constexpr uint32_t W_POS_R = plant_const(POS_R);                          // plant(a, W_POS_R) = a * 2^32 mod q: plant2 of it is the NEGATED product
 
 // The two halves of plant(), apart so that a stage can issue them grouped by kind. UNIFORM_W: W lives in an SGPR.
 template <bool UNIFORM_W>
