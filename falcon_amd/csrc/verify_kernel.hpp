@@ -113,6 +113,13 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Region marks in the device assembly (comments only), for counting instructions per region: -DFA_MARKS
+#ifdef FA_MARKS
+#define FA_MARK(name) asm volatile("; FA_MARK " name)
+#else
+#define FA_MARK(name)
+#endif
+
 __device__ __forceinline__ void wave_lds_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -518,25 +525,6 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
     const uint32_t d = t * 64u + lane;
     r.hw[t] = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are always rejected
   }
-  // s2 is tiled (chunk stride 64*32, see decode_kernel.hpp): coefficient i = 64 m + lane sits at row base + m * 4096 +
-  // (lane >> 5) * 2048 + (lane & 31). The per-m bases are wave-uniform: a load should be SGPR base + one VGPR offset
-  // shared by all m. Left alone hipcc adds the lane offset to the row base first and then builds eight 64-bit
-  // addresses with vector adds; the empty asm pins each base to an SGPR pair before the offset is added (it emits nothing).
-  const uint16_t* s2row = A.s2 + s2_tile_offset<LOGN>(slot, 0u);
-  if constexpr (LOGN == 9) {
-    uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes: a 32-bit byte offset is what the load takes
-    asm volatile("" : "+v"(lane_off));  // keeps its zero extension in this basic block, where instruction selection can fold it
-#pragma unroll
-    for (int m = 0; m < G::R; m++) {
-      const uint16_t* base_m = s2row + (size_t)m * 4096u;
-      asm volatile("" : "+s"(base_m));
-      typedef const char __attribute__((address_space(1))) * global_bytes;  // still global memory after the asm: global_load, not flat_load
-      r.s2v[m] = *(const uint16_t __attribute__((address_space(1)))*)((global_bytes)base_m + lane_off);
-    }
-  } else {  // Falcon-1024 has no SGPRs to spare for 16 bases (they spill to VGPR lanes, measured +1 %): the compiler's way
-#pragma unroll
-    for (int m = 0; m < G::R; m++) r.s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];
-  }
   if constexpr (PREPARED) {
     r.pal = 0u;  // (the key row was requested first, above)
   } else {
@@ -552,6 +540,34 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   }
   r.sqn = A.sqn[slot];
   r.st = A.st2[slot];
+}
+
+// The s2 part of an item's loads, apart from the rest: its registers are the ones the item's first transform works in,
+// so they are free (and the next item's s2 can be requested) only once the pointwise product has been formed.
+template <int LOGN>
+__device__ __forceinline__ void prefetch_s2(const uint16_t* __restrict__ s2, uint32_t slot, uint32_t lane, uint32_t (&s2v)[Geo<LOGN>::R])
+{
+  using G = Geo<LOGN>;
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  // s2 is tiled (chunk stride 64*32, see decode_kernel.hpp): coefficient i = 64 m + lane sits at row base + m * 4096 +
+  // (lane >> 5) * 2048 + (lane & 31). The per-m bases are wave-uniform: a load should be SGPR base + one VGPR offset
+  // shared by all m. Left alone hipcc adds the lane offset to the row base first and then builds eight 64-bit
+  // addresses with vector adds; the empty asm pins each base to an SGPR pair before the offset is added (it emits nothing).
+  const uint16_t* s2row = s2 + s2_tile_offset<LOGN>(slot, 0u);
+  if constexpr (LOGN == 9) {
+    uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes: a 32-bit byte offset is what the load takes
+    asm volatile("" : "+v"(lane_off));  // keeps its zero extension in this basic block, where instruction selection can fold it
+#pragma unroll
+    for (int m = 0; m < G::R; m++) {
+      const uint16_t* base_m = s2row + (size_t)m * 4096u;
+      asm volatile("" : "+s"(base_m));
+      typedef const char __attribute__((address_space(1))) * global_bytes;  // still global memory after the asm: global_load, not flat_load
+      s2v[m] = *(const uint16_t __attribute__((address_space(1)))*)((global_bytes)base_m + lane_off);
+    }
+  } else {  // Falcon-1024 has no SGPRs to spare for 16 bases (they spill to VGPR lanes, measured +1 %): the compiler's way
+#pragma unroll
+    for (int m = 0; m < G::R; m++) s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];
+  }
 }
 
 // PREPARED: the public key arrives as NTT(h) (prepare_keys_kernel) instead of packed bytes -- the
@@ -575,12 +591,27 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
   if (slot >= count) return;
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED, GENERAL>(A, slot, lane, cur);
+  prefetch_s2<LOGN>(A.s2, slot, lane, cur.s2v);
+  {
+    // The loop below carries cur.s2v from one iteration to the next. If every value that enters it is a zero-extended
+    // 16-bit load, hipcc carries 16-bit values and extends them where they are used -- a v_and per coefficient and item,
+    // although the load instruction has already cleared the upper half. One value of another kind (this first set,
+    // combined with a zero the compiler cannot see through; once per wave) keeps the carried values at 32 bits.
+    uint32_t opaque_zero = 0u;
+    asm volatile("" : "+v"(opaque_zero));
+#pragma unroll
+    for (int m = 0; m < R; m++) cur.s2v[m] |= opaque_zero;
+  }
 
-  // One register set: an item's loaded words are consumed at the top of its iteration (sampling, s2 into x[], key fields
-  // into y[]), and the NEXT item's loads are then issued straight into the same registers, to arrive behind this item's
+  // One register set: an item's loaded words are consumed at the top of its iteration (sampling, key fields into y[]),
+  // and the NEXT item's loads are then issued straight into the same registers, to arrive behind this item's
   // transforms. (Round 1 kept two sets and copied nxt into cur at the end of every iteration: 21 v_mov per item and 21
   // more live registers.) The loads are waited for once, at the top of the iteration that uses them.
+  // s2 is the exception: its registers ARE x[], the array the first transform works in (no copy), so the next item's
+  // s2 is requested when x[] is dead -- after the pointwise product, whose result goes to y[] -- and arrives behind the
+  // inverse transform and the epilogue.
   while (true) {
+    FA_MARK("top");
     vmem_wait_all();
     const uint32_t item = __builtin_amdgcn_readfirstlane(cur.item);
     const uint32_t sqn = __builtin_amdgcn_readfirstlane(cur.sqn);
@@ -593,6 +624,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       if (hdr != (uint32_t)LOGN) status = ST_BAD_PK_HEADER;  // checked before the signature, as the reference does
     }
 
+    FA_MARK("sampling");
     bool done = false;
     uint32_t have = 0;  // accepted draws so far (wave-uniform)
     if (status == ST_OK) {
@@ -639,12 +671,12 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
 
     // ---- what the transforms need, out of the loaded words: s2 (already lifted to [0,q), verification.hpp:36-39) and
     //      the key ----
+    FA_MARK("unpack");
     const bool run = status == ST_OK && !done;
-    uint32_t x[R], y[R];
+    uint32_t (&x)[R] = cur.s2v;  // the first transform works in the registers the loads filled
+    uint32_t y[R];
     uint32_t hk[PREPARED ? R / 2 : 1], s2keep[DEBUG ? R : 1];
     if (run) {
-#pragma unroll
-      for (int m = 0; m < R; m++) x[m] = cur.s2v[m];
       if constexpr (DEBUG) {
 #pragma unroll
         for (int m = 0; m < R; m++) s2keep[m] = cur.s2v[m];
@@ -659,11 +691,14 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         unpack_pkey<LOGN>(cur.pkw, cur.pal, pkb, lane, y);
       }
     }
+    FA_MARK("prefetch");
     // cur's registers are free: the next item's loads
     const uint32_t nslot = slot + nwaves;
     const bool more = nslot < count;  // wave-uniform
     if (more) prefetch_item<LOGN, PREPARED, GENERAL>(A, nslot, lane, cur);
+    bool s2_requested = false;
 
+    FA_MARK("branch");
     if (status != ST_OK) {
       if (lane == 0) {
         A.accept[item] = 0;
@@ -687,28 +722,38 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
 #pragma unroll
         for (int m = 0; m < R; m++) {  // 2^32 NTT(h), canonical, already in this lane's phase-C positions
           const uint32_t hv = (hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
-          x[m] = plant2(x[m], hv);  // MINUS the product of polynomial.hpp:99-110; x < 2^16 + 2 logn q, hv < q: below 2^32
+          y[m] = plant2(x[m], hv);  // MINUS the product of polynomial.hpp:99-110; x < 2^16 + 2 logn q, hv < q: below 2^32
         }
       } else {
         // One transform after the other: interleaving them (ntt_forward2) costs Falcon-1024 its third wave per SIMD
         // (31 more VGPRs, 17 KB more LDS) and, with the stages grouped by instruction kind, is 13 % slower.
+        FA_MARK("ntt_y");
         ntt_forward<LOGN>(y, T, buf, lane);
+        FA_MARK("ntt_x");
         ntt_forward<LOGN>(x, T, buf, lane);
+        FA_MARK("pointwise");
 #pragma unroll
         for (int m = 0; m < R; m++) x[m] = plant(x[m], W_POS_R);  // canonical, times 2^32
 #pragma unroll
-        for (int m = 0; m < R; m++) x[m] = plant2(x[m], y[m]);    // MINUS the product of polynomial.hpp:99-110; y < 16384 + 2 logn q
+        for (int m = 0; m < R; m++) y[m] = plant2(x[m], y[m]);    // MINUS the product of polynomial.hpp:99-110; y < 16384 + 2 logn q
       }
-      ntt_inverse<LOGN, false>(x, T, buf, lane);  // sc[i] * x = -s2*h mod q, natural order, phase-A layout; x lazy
+      // x[] is dead: the next item's s2, into the same registers. Not under `if (more)`: a conditional load would keep the
+      // old values alive beside x[] (they would be what the registers hold on the other path) and bring the copy back;
+      // the last iteration loads its own row once more instead.
+      prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);
+      s2_requested = true;
+      FA_MARK("intt");
+      ntt_inverse<LOGN, false>(y, T, buf, lane);  // sc[i] * y = -s2*h mod q, natural order, phase-A layout; y lazy
 
       // ---- s1 = c - s2*h, centred; squared norm (verification.hpp:53-79) ----
-      // s1 = craw + sc*x (mod q), a sum of non-negative values. The centred value v lies in [half - q, half - 1]
+      // s1 = craw + sc*y (mod q), a sum of non-negative values. The centred value v lies in [half - q, half - 1]
       // (verification.hpp:59-68: values >= half = 6144 go negative; the specification's centring has half = 6145), so
-      // v + (q - half) is the canonical residue of u = craw + (q - half) + sc*x -- and that is ONE Plantard reduction:
-      // the low products are linear, low(x * W_sc) + low(u0 * W_one) is the low product of the sum, and the high product
-      // by q reduces it (zq.hpp; exact because x * q + u0 * 1337 < 258,069 q + 79,878 * 1337 < 2^32). Per coefficient:
+      // v + (q - half) is the canonical residue of u = craw + (q - half) + sc*y -- and that is ONE Plantard reduction:
+      // the low products are linear, low(y * W_sc) + low(u0 * W_one) is the low product of the sum, and the high product
+      // by q reduces it (zq.hpp; exact because y * q + u0 * 1337 < 258,069 q + 79,878 * 1337 < 2^32). Per coefficient:
       // low product, add, multiply-add, high product, subtract, multiply-add -- no comparison, no select, and the
       // inverse transform's final scaling costs nothing of its own.
+      FA_MARK("epilogue");
       uint32_t acc = 0;
       const uint32_t shift = Q - A.half;
       static_assert((2ull * LOGN + 1ull) * Q * (Q - 1ull) + (61444ull + Q) * NEG_R < (1ull << 32), "fused scaling and reduction");
@@ -719,7 +764,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         for (int k = 0; k < 8; k++) craw[k] = cbuf[idxA<LOGN>(lane, m0 + k)];  // < 61445
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = plant_lo<false>(x[m0 + k], T.sc[(m0 + k) << 6]);
+        for (int k = 0; k < 8; k++) w[k] = plant_lo<false>(y[m0 + k], T.sc[(m0 + k) << 6]);
         valu_fence();
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] += __umul24(craw[k] + shift, W_ONE);
@@ -732,7 +777,9 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
           const int m = m0 + k;
           const uint32_t i = idxA<LOGN>(lane, m);
           const int32_t v = (int32_t)w[k] - (int32_t)shift;                    // centred s1
-          acc += (uint32_t)__mul24(v, v);                                      // |v| <= 6145
+          // acc += v * v (|v| <= 6145), stated as the one instruction it is: left to itself hipcc multiplies the eight
+          // squares apart and adds them up in threes, eleven instructions instead of eight
+          asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(acc) : "v"(v));
           if (DEBUG) {
             if (A.dbg.c) A.dbg.c[(size_t)item * N + i] = (uint16_t)mod_q_17(craw[k]);
             if (A.dbg.s1) A.dbg.s1[(size_t)item * N + i] = (int16_t)v;
@@ -743,6 +790,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
           }
         }
       }
+      FA_MARK("norm");
       // per-lane sums are < 2^30 but the wave total needs 36 bits: reduce the low 24 bits and the rest apart
       unsigned long long total = (unsigned long long)wave_sum_u32(acc & 0xffffffu) +
                                  ((unsigned long long)wave_sum_u32(acc >> 24) << 24);
@@ -758,7 +806,9 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         }
       }
     }
+    if (!s2_requested) prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);  // items that ran no transform
     wave_lds_sync();  // cbuf / pkb / buf are reused by the next item
+    FA_MARK("end");
     if (!more) break;
     slot = nslot;
   }
