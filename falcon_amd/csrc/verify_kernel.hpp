@@ -554,19 +554,14 @@ __device__ __forceinline__ void prefetch_s2(const uint16_t* __restrict__ s2, uin
   // shared by all m. Left alone hipcc adds the lane offset to the row base first and then builds eight 64-bit
   // addresses with vector adds; the empty asm pins each base to an SGPR pair before the offset is added (it emits nothing).
   const uint16_t* s2row = s2 + s2_tile_offset<LOGN>(slot, 0u);
-  if constexpr (LOGN == 9) {
-    uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes: a 32-bit byte offset is what the load takes
-    asm volatile("" : "+v"(lane_off));  // keeps its zero extension in this basic block, where instruction selection can fold it
+  uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes: a 32-bit byte offset is what the load takes
+  asm volatile("" : "+v"(lane_off));  // keeps its zero extension in this basic block, where instruction selection can fold it
 #pragma unroll
-    for (int m = 0; m < G::R; m++) {
-      const uint16_t* base_m = s2row + (size_t)m * 4096u;
-      asm volatile("" : "+s"(base_m));
-      typedef const char __attribute__((address_space(1))) * global_bytes;  // still global memory after the asm: global_load, not flat_load
-      s2v[m] = *(const uint16_t __attribute__((address_space(1)))*)((global_bytes)base_m + lane_off);
-    }
-  } else {  // Falcon-1024 has no SGPRs to spare for 16 bases (they spill to VGPR lanes, measured +1 %): the compiler's way
-#pragma unroll
-    for (int m = 0; m < G::R; m++) s2v[m] = s2row[(2u * m + (lane >> 5)) * 2048u + (lane & 31u)];
+  for (int m = 0; m < G::R; m++) {
+    const uint16_t* base_m = s2row + (size_t)m * 4096u;
+    asm volatile("" : "+s"(base_m));
+    typedef const char __attribute__((address_space(1))) * global_bytes;  // still global memory after the asm: global_load, not flat_load
+    s2v[m] = *(const uint16_t __attribute__((address_space(1)))*)((global_bytes)base_m + lane_off);
   }
 }
 
@@ -696,7 +691,6 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
     const uint32_t nslot = slot + nwaves;
     const bool more = nslot < count;  // wave-uniform
     if (more) prefetch_item<LOGN, PREPARED, GENERAL>(A, nslot, lane, cur);
-    bool s2_requested = false;
 
     FA_MARK("branch");
     if (status != ST_OK) {
@@ -737,11 +731,14 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
 #pragma unroll
         for (int m = 0; m < R; m++) y[m] = plant2(x[m], y[m]);    // MINUS the product of polynomial.hpp:99-110; y < 16384 + 2 logn q
       }
-      // x[] is dead: the next item's s2, into the same registers. Not under `if (more)`: a conditional load would keep the
-      // old values alive beside x[] (they would be what the registers hold on the other path) and bring the copy back;
-      // the last iteration loads its own row once more instead.
-      prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);
-      s2_requested = true;
+    }
+    // x[] is dead: the next item's s2, into the same registers. One place for every path (an item that ran no transform
+    // passes here too): loads in two places would meet as 16-bit values and be extended after the join, a v_and per
+    // coefficient. Not under `if (more)` either: a conditional load would keep the old values alive beside x[] (they
+    // would be what the registers hold on the other path) and bring the copy back; the last iteration loads its own
+    // row once more instead.
+    prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);
+    if (run) {
       FA_MARK("intt");
       ntt_inverse<LOGN, false>(y, T, buf, lane);  // sc[i] * y = -s2*h mod q, natural order, phase-A layout; y lazy
 
@@ -806,7 +803,6 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         }
       }
     }
-    if (!s2_requested) prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);  // items that ran no transform
     wave_lds_sync();  // cbuf / pkb / buf are reused by the next item
     FA_MARK("end");
     if (!more) break;
