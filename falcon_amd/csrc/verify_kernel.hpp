@@ -120,6 +120,10 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 #define FA_MARK(name)
 #endif
 
+// The wave's number within its workgroup, as a scalar: addresses derived from it (the wave's LDS buffers) are then
+// scalar too and fold into instructions as operands instead of occupying vector registers and adds.
+__device__ __forceinline__ uint32_t wave_index() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 __device__ __forceinline__ void wave_lds_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(VERIFY_WG) void prepare_keys_kernel(const uint8_t* 
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
   fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < nkeys; key += gridDim.x * VERIFY_WAVES) {
     uint32_t y[R];
@@ -544,25 +548,38 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
 
 // The s2 part of an item's loads, apart from the rest: its registers are the ones the item's first transform works in,
 // so they are free (and the next item's s2 can be requested) only once the pointwise product has been formed.
+//
+// s2 is tiled (chunk stride 64*32, see decode_kernel.hpp): coefficient i = 64 m + lane sits at row base + m * 4096 +
+// (lane >> 5) * 2048 + (lane & 31). The per-m bases are wave-uniform: each load is SGPR base + one VGPR byte offset
+// shared by all m.
+//
+// The loads are written as instructions, not as C++ loads, because of what hipcc does with the C++ form: the values
+// are carried around the item loop as 16-bit quantities and zero-extended where the loop closes -- a v_and per
+// coefficient and item for something global_load_ushort has already done -- and Falcon-1024's sixteen addresses were
+// built with 64-bit vector adds (31 instructions per item). The price: the compiler does not know these registers are
+// the targets of loads in flight. s2_arrived() is the only thing that may touch them after prefetch_s2(): it waits
+// for all vector memory operations and then hands the registers back to the compiler as ordinary values. The two
+// calls bracket straight-line code in which the values have no other use; tools/check_asm_loads.py (run by build.sh on
+// the device assembly) checks that nothing reads or writes the target registers between a load and the wait.
 template <int LOGN>
 __device__ __forceinline__ void prefetch_s2(const uint16_t* __restrict__ s2, uint32_t slot, uint32_t lane, uint32_t (&s2v)[Geo<LOGN>::R])
 {
   using G = Geo<LOGN>;
   slot = __builtin_amdgcn_readfirstlane(slot);
-  // s2 is tiled (chunk stride 64*32, see decode_kernel.hpp): coefficient i = 64 m + lane sits at row base + m * 4096 +
-  // (lane >> 5) * 2048 + (lane & 31). The per-m bases are wave-uniform: a load should be SGPR base + one VGPR offset
-  // shared by all m. Left alone hipcc adds the lane offset to the row base first and then builds eight 64-bit
-  // addresses with vector adds; the empty asm pins each base to an SGPR pair before the offset is added (it emits nothing).
   const uint16_t* s2row = s2 + s2_tile_offset<LOGN>(slot, 0u);
-  uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes: a 32-bit byte offset is what the load takes
-  asm volatile("" : "+v"(lane_off));  // keeps its zero extension in this basic block, where instruction selection can fold it
+  const uint32_t lane_off = ((lane >> 5) * 2048u + (lane & 31u)) * 2u;  // in bytes
 #pragma unroll
   for (int m = 0; m < G::R; m++) {
     const uint16_t* base_m = s2row + (size_t)m * 4096u;
-    asm volatile("" : "+s"(base_m));
-    typedef const char __attribute__((address_space(1))) * global_bytes;  // still global memory after the asm: global_load, not flat_load
-    s2v[m] = *(const uint16_t __attribute__((address_space(1)))*)((global_bytes)base_m + lane_off);
+    asm volatile("global_load_ushort %0, %1, %2 ; FA_ASM_LOAD" : "=v"(s2v[m]) : "v"(lane_off), "s"(base_m));
   }
+}
+template <int LOGN>
+__device__ __forceinline__ void s2_arrived(uint32_t (&s2v)[Geo<LOGN>::R])
+{
+  asm volatile("s_waitcnt vmcnt(0) ; FA_ASM_LOAD_WAIT" ::: "memory");
+#pragma unroll
+  for (int m = 0; m < Geo<LOGN>::R; m++) asm volatile("" : "+v"(s2v[m]));
 }
 
 // PREPARED: the public key arrives as NTT(h) (prepare_keys_kernel) instead of packed bytes -- the
@@ -587,16 +604,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED, GENERAL>(A, slot, lane, cur);
   prefetch_s2<LOGN>(A.s2, slot, lane, cur.s2v);
-  {
-    // The loop below carries cur.s2v from one iteration to the next. If every value that enters it is a zero-extended
-    // 16-bit load, hipcc carries 16-bit values and extends them where they are used -- a v_and per coefficient and item,
-    // although the load instruction has already cleared the upper half. One value of another kind (this first set,
-    // combined with a zero the compiler cannot see through; once per wave) keeps the carried values at 32 bits.
-    uint32_t opaque_zero = 0u;
-    asm volatile("" : "+v"(opaque_zero));
-#pragma unroll
-    for (int m = 0; m < R; m++) cur.s2v[m] |= opaque_zero;
-  }
+  s2_arrived<LOGN>(cur.s2v);  // once per wave: the first item's s2 is waited for here
 
   // One register set: an item's loaded words are consumed at the top of its iteration (sampling, key fields into y[]),
   // and the NEXT item's loads are then issued straight into the same registers, to arrive behind this item's
@@ -635,12 +643,14 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         const bool a0 = (p & 0xffffu) < 61445u, a1 = p < (61445u << 16);
         const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
         // both draws of a lane come after all draws of the lanes below it: one prefix count over each mask, chained
+        // (the count so far, `have`, is a scalar: it goes into the address, not into the prefix count's vector operand)
         const uint32_t p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
-                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, have))));
-        uint16_t* dst = cbuf + p0;
-        if (a0 && (bounded || p0 < (uint32_t)N)) dst[0] = (uint16_t)p;
-        if (a1 && a0 && (bounded || p0 + 1u < (uint32_t)N)) dst[1] = (uint16_t)(p >> 16);
-        if (a1 && !a0 && (bounded || p0 < (uint32_t)N)) dst[0] = (uint16_t)(p >> 16);
+                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))));
+        uint16_t* dst = (cbuf + have) + p0;
+        const uint32_t room = (uint32_t)N - have;  // > 0
+        if (a0 && (bounded || p0 < room)) dst[0] = (uint16_t)p;
+        if (a1 && a0 && (bounded || p0 + 1u < room)) dst[1] = (uint16_t)(p >> 16);
+        if (a1 && !a0 && (bounded || p0 < room)) dst[0] = (uint16_t)(p >> 16);
         have += __popcll(m0) + __popcll(m1);
       };
 #pragma unroll
@@ -733,10 +743,10 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       }
     }
     // x[] is dead: the next item's s2, into the same registers. One place for every path (an item that ran no transform
-    // passes here too): loads in two places would meet as 16-bit values and be extended after the join, a v_and per
-    // coefficient. Not under `if (more)` either: a conditional load would keep the old values alive beside x[] (they
-    // would be what the registers hold on the other path) and bring the copy back; the last iteration loads its own
-    // row once more instead.
+    // passes here too). Not under `if (more)`: a conditional load would keep the old values alive beside x[] (they
+    // would be what the registers hold on the other path) and bring a copy back; the last iteration loads its own
+    // row once more instead. The loads arrive behind the inverse transform and the epilogue; s2_arrived() at the end
+    // of the iteration waits for them.
     prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);
     if (run) {
       FA_MARK("intt");
@@ -803,6 +813,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         }
       }
     }
+    s2_arrived<LOGN>(cur.s2v);
     wave_lds_sync();  // cbuf / pkb / buf are reused by the next item
     FA_MARK("end");
     if (!more) break;
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(64 * verify_waves<LOGN>()) void verify_kernel(const
   __shared__ uint32_t s_buf[VW][G::XBUF];  // transposes
   __shared__ uint16_t s_c[VW][G::N];
   fill_tw_lds<LOGN>(s_tw, A.tw, A.itw, A.twc, A.isc);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   const TwTabs T = make_tabs<LOGN>(s_tw, A.nc, lane);
   const uint32_t count = GENERAL && A.dcount ? min(A.count, *A.dcount) : A.count;
   verify_items<LOGN, DEBUG, PREPARED, GENERAL>(A, T, s_buf[wave], s_c[wave], lane, blockIdx.x * VW + wave, gridDim.x * VW, count);
@@ -836,7 +847,7 @@ __global__ __launch_bounds__(VERIFY_WG) void sample_kernel(const uint64_t* __res
 {
   constexpr uint32_t N = 1u << LOGN;
   __shared__ uint16_t s_c[VERIFY_WAVES][N];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   uint16_t* cbuf = s_c[wave];
   const uint32_t ndw = nblk * 34u;
   for (uint32_t slot = blockIdx.x * VERIFY_WAVES + wave; slot < count; slot += gridDim.x * VERIFY_WAVES) {
@@ -885,7 +896,7 @@ __global__ __launch_bounds__(VERIFY_WG) void pubkey_kernel(const int32_t* __rest
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
   fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < count; key += gridDim.x * VERIFY_WAVES) {
     uint32_t x[R], y[R];
@@ -930,7 +941,7 @@ __global__ __launch_bounds__(VERIFY_WG) void ntt_kernel(const uint16_t* __restri
   __shared__ TwLds<LOGN> s_tw;
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   for (uint32_t p = blockIdx.x * VERIFY_WAVES + wave; p < count; p += gridDim.x * VERIFY_WAVES) {
     uint32_t x[R];
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(VERIFY_WG) void decode_pkeys_kernel(const uint8_t* 
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
   __shared__ uint32_t s_pk[VERIFY_WAVES][G::PKDW * 64];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   for (uint32_t key = blockIdx.x * VERIFY_WAVES + wave; key < nkeys; key += gridDim.x * VERIFY_WAVES) {
     const uint8_t* pkrow = pk + (size_t)key * G::PKLEN;
     const uint32_t pal = (uint32_t)((uintptr_t)pkrow & 3u);
@@ -1030,7 +1041,7 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
   __shared__ uint32_t s_buf[VERIFY_WAVES][G::XBUF];
   __shared__ uint32_t s_buf2[VERIFY_WAVES][G::XBUF];
   fill_tw_lds<LOGN>(s_tw, tw, itw, twc, isc);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = wave_index();
   uint32_t* buf = s_buf[wave];
   const TwTabs T = make_tabs<LOGN>(s_tw, nc, lane);
   const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
