@@ -48,10 +48,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # signature decoding 10 per coefficient. By construction these are <= what the kernels issue, so achieved / peak <= 1.
 # REF_OPS is SURVEY.md 8(d)'s model of the REFERENCE's work (11 per butterfly, 4 transforms), reported beside it only.
 # Round 3: a butterfly is 4 (two-instruction Plantard product, add, subtract); the inverse transform's first stage
-# multiplies nothing (2 per butterfly) and its last step is one product per coefficient.
+# multiplies nothing (2 per butterfly); its final scaling is part of the epilogue's one reduction (6 per coefficient:
+# low product, add, multiply-add, high product, subtract, multiply-add); pointwise 5 (reduction + product), key unpack 2,
+# 3 per draw of the rejection sampling.
 def _verify_ops(n, logn, draws):
     bf = n // 2 * logn                     # butterflies per transform
-    return 2 * bf * 4 + ((bf - n // 2) * 4 + n // 2 * 2 + n * 2) + n * 5 + n * 2 + n * 6 + draws * 3
+    return 2 * bf * 4 + ((bf - n // 2) * 4 + n // 2 * 2) + n * 5 + n * 2 + n * 6 + draws * 3
 
 
 ALG_OPS = {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Large differential run on the GPU box: HIP path (through the C ABI) against the CPU oracle, item by item, on seeded
 corpora with half of the items malformed (all 12 classes of SURVEY.md 8d), both norm policies; the debug outputs (status,
-exact and wrapped norm) are compared on every item as well. Usage: python tools/fuzz_big.py [items_512] [items_1024]"""
+exact and wrapped norm) are compared on every item as well. Usage: python tools/fuzz_big.py [items_512] [items_1024] [seed]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,7 @@ from falcon_amd import capi
 
 n9 = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
 n10 = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 21
+seed = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0xF0323
 ctx = capi.Context(0)
 orc = support.oracle()
 out = {}
@@ -25,7 +26,7 @@ for logn, total in ((9, n9), (10, n10)):
     step = 1 << 19
     for first in range(0, total, step):
         n = min(step, total - first)
-        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=0xF0323 + logn, first=first, mlen=32, malformed_permille=500, threads=16)
+        pk, msg, sig, kinds = support.corpus().generate(logn, n, seed=seed + logn, first=first, mlen=32, malformed_permille=500, threads=16)
         flags, odbg = orc.verify_many(logn, pk, msg, sig, debug=True, threads=16)
         acc, gdbg = ctx.verify_many(logn, pk, msg, sig, debug=True)
         accw = ctx.verify_many(logn, pk, msg, sig, norm_policy=1)
@@ -100,5 +101,6 @@ for logn, total in ((9, n9), (10, n10)):
         print(f"Falcon-{1 << logn}: {done}/{total} items, mismatches so far {bad}", flush=True)
     out[f"falcon{1 << logn}"] = {"items": done, "malformed_share": 1 - classes.get(0, 0) / done, "items_per_class": classes,
                                  "mismatches": bad, "seconds": round(time.time() - t0, 1)}
+out["seed"] = seed
 print(json.dumps(out))
 sys.exit(1 if any(v for r in out.values() for v in r["mismatches"].values()) else 0)
