@@ -284,11 +284,38 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const Rows& sig
   if (slot0 >= count) return;
   const bool live = slot < count;
   const uint32_t row = live ? slot : count - 1u;  // idle lanes shadow the last row and write nothing
-  // signature body of workspace slot r (slot -> item through idx, item -> address through sig)
-  auto body_of = [&](uint32_t r) -> const uint8_t* { return sig.at(idx ? idx[r] : r) + 41; };
+  // The signature bodies this lane deals with (slot -> item through idx, item -> address through sig): its own row's, the
+  // eight rows' it helps to load in the prologue, the four rows' it helps to refill. All thirteen addresses are formed
+  // here, the optional index and offset loads of all of them under ONE test each: written per row (test, load, use) every
+  // row's address waited for the previous row's loads -- the optional loads meet the unconditional ones at a join, and
+  // hipcc waits for everything outstanding there even on the path that loaded nothing -- so the eight piece loads of the
+  // prologue went out one HBM round trip after the other at the start of every wave.
+  const uint8_t* bodies[13];
+  {
+    uint32_t rws[13], items[13];
+    rws[0] = row;
+#pragma unroll
+    for (int t = 0; t < 8; t++) rws[1 + t] = min(slot0 + 8u * t + (lane >> 3), count - 1u);
+#pragma unroll
+    for (int t = 0; t < 4; t++) rws[9 + t] = min(slot0 + 16u * t + (lane >> 2), count - 1u);
+    if (idx) {
+#pragma unroll
+      for (int i = 0; i < 13; i++) items[i] = idx[rws[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 13; i++) items[i] = rws[i];
+    }
+    if (sig.off) {
+#pragma unroll
+      for (int i = 0; i < 13; i++) bodies[i] = sig.base + (size_t)sig.off[items[i]] + 41;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 13; i++) bodies[i] = sig.base + (size_t)items[i] * sig.stride + 41;
+    }
+  }
 
   // geometry of this lane's row, relative to the 16-byte aligned address at or below the body (`lbase` below)
-  const uint8_t* body = body_of(row);
+  const uint8_t* body = bodies[0];
   const uint32_t boff = (uint32_t)((uintptr_t)body & 15u);
   const uint32_t end_bits = 8u * (boff + BODY);        // first bit past the signature
   const uint32_t plast = (boff + BODY - 1u) >> 4;      // last piece holding a byte of the row (never read past it)
@@ -315,7 +342,7 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const Rows& sig
     uint4 v[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      const uint8_t* b = body_of(min(slot0 + 8u * t + (lane >> 3), count - 1u));
+      const uint8_t* b = bodies[1 + t];
       const uint32_t last = ((uint32_t)((uintptr_t)b & 15u) + BODY - 1u) >> 4;
       v[t] = ((const uint4*)(b - ((uintptr_t)b & 15u)))[min(lane & 7u, last)];  // lanes 6, 7 of a group load too (and drop it):
     }                                                                          // unconditional loads issue back to back
@@ -339,7 +366,7 @@ __device__ __forceinline__ void decode_fast_body(uint32_t block, const Rows& sig
   const uint4* lbase[4];  // aligned base of the row this lane helps to load in round t
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const uint8_t* b = body_of(min(slot0 + 16u * t + (lane >> 2), count - 1u));
+    const uint8_t* b = bodies[9 + t];
     lbase[t] = (const uint4*)(b - ((uintptr_t)b & 15u));
   }
   uint32_t want = 0;
