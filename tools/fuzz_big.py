@@ -101,6 +101,59 @@ for logn, total in ((9, n9), (10, n10)):
         print(f"Falcon-{1 << logn}: {done}/{total} items, mismatches so far {bad}", flush=True)
     out[f"falcon{1 << logn}"] = {"items": done, "malformed_share": 1 - classes.get(0, 0) / done, "items_per_class": classes,
                                  "mismatches": bad, "seconds": round(time.time() - t0, 1)}
+
+# ---- ragged messages and mixed batches (the GENERAL kernel instantiations: records through offset arrays) ----
+# Corpora of several message lengths around the sponge's block boundaries (0, 1, 95/96/97 = one absorb block with the
+# salt exactly full, 135..137, 300 bytes), their records shuffled into one flat batch; then a Falcon-512 / Falcon-1024
+# mix of the same kind through fa_verify_mixed. The oracle runs per class on the same bytes.
+t0 = time.time()
+rng = np.random.default_rng(seed)
+parts, nrag = [], 1 << 15
+for logn in (9, 10):
+    for j, ml in enumerate((0, 1, 31, 95, 96, 97, 135, 136, 137, 300)):
+        pk, msg, sig, _ = support.corpus().generate(logn, nrag, seed=seed + 977 * logn + j, mlen=ml, malformed_permille=400, threads=16)
+        flags, _ = orc.verify_many(logn, pk, msg, sig, threads=16)
+        parts.append((logn, ml, pk, msg.reshape(nrag, ml), sig, flags))
+bad = {"accept_ragged_512": 0, "accept_ragged_1024": 0, "accept_ragged_keyset": 0, "accept_mixed": 0, "accept_mixed_wrap32": 0}
+total_rag = 0
+for logn in (9, 10):
+    mine = [p for p in parts if p[0] == logn]
+    order = rng.permutation(len(mine) * nrag)
+    pk = np.concatenate([p[2] for p in mine])[order]
+    sig = np.concatenate([p[4] for p in mine])[order]
+    want = np.concatenate([p[5] for p in mine])[order]
+    lens = np.concatenate([np.full(nrag, p[1], np.uint64) for p in mine])[order]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    flat = np.zeros(int(off[-1]), np.uint8)
+    src = [p[3] for p in mine]
+    for i, o in enumerate(order):   # scatter the messages into the flat buffer in batch order
+        ml = int(lens[i])
+        if ml:
+            flat[int(off[i]):int(off[i]) + ml] = src[o // nrag][o % nrag]
+    got = ctx.verify_many(logn, pk, flat, sig, msg_off=off)
+    bad[f"accept_ragged_{1 << logn}"] += int((got != (want & 1)).sum())
+    if logn == 9:
+        ks = ctx.keyset_create(9, pk=pk)
+        bad["accept_ragged_keyset"] += int((ctx.verify_many_keyset(ks, flat, sig, msg_off=off) != (want & 1)).sum())
+        ks.close()
+    total_rag += len(order)
+# mixed: every record of both classes in one shuffled batch, offsets into three flat arrays
+recs = [(p[0], p[2][i], p[3][i], p[4][i], p[5][i]) for p in parts for i in range(0, nrag, 8)]
+order = rng.permutation(len(recs))
+lg = np.array([recs[o][0] for o in order], np.uint8)
+pk_off = np.concatenate([[0], np.cumsum([recs[o][1].size for o in order])]).astype(np.uint64)
+sig_off = np.concatenate([[0], np.cumsum([recs[o][3].size for o in order])]).astype(np.uint64)
+msg_off = np.concatenate([[0], np.cumsum([recs[o][2].size for o in order])]).astype(np.uint64)
+pkf = np.concatenate([recs[o][1] for o in order])
+sigf = np.concatenate([recs[o][3] for o in order])
+msgf = np.concatenate([recs[o][2] for o in order]) if msg_off[-1] else np.zeros(0, np.uint8)
+want = np.array([recs[o][4] for o in order], np.uint8)
+bad["accept_mixed"] += int((ctx.verify_mixed(lg, pkf, pk_off[:-1], msgf, msg_off, sigf, sig_off[:-1]) != (want & 1)).sum())
+bad["accept_mixed_wrap32"] += int((ctx.verify_mixed(lg, pkf, pk_off[:-1], msgf, msg_off, sigf, sig_off[:-1], norm_policy=1) != ((want >> 1) & 1)).sum())
+out["ragged_and_mixed"] = {"items": total_rag + len(order), "ragged_items": total_rag, "mixed_items": int(len(order)),
+                           "message_lengths": [0, 1, 31, 95, 96, 97, 135, 136, 137, 300], "mismatches": bad,
+                           "seconds": round(time.time() - t0, 1)}
+print(f"ragged and mixed: {out['ragged_and_mixed']}", flush=True)
 out["seed"] = seed
 print(json.dumps(out))
-sys.exit(1 if any(v for r in out.values() for v in r["mismatches"].values()) else 0)
+sys.exit(1 if any(v for r in out.values() if isinstance(r, dict) for v in r["mismatches"].values()) else 0)
