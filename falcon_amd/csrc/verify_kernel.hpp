@@ -26,6 +26,8 @@
 // the first stage of a transform adds BIAS = logn*q to its sums' inputs once; nothing is reduced in between:
 //   forward: inputs < 2^16            ->  outputs in [0, 2^16 + 2 logn q) < 311,316
 //   inverse: inputs <= q              ->  before the final scaling in [0, (2 logn + 1) q) <= 258,069;  after it < q
+// (the verify kernel itself leaves the inverse transform before that scaling: its epilogue does scaling, the addition
+// of c and the centring's reduction in ONE Plantard product, see verify_items)
 //
 // Data layout inside a wave (n = 64*R coefficients, R = 8 or 16 per lane, LB = log2 R):
 //   phase A  lane = i & 63,                     regs hold index bits [6, logn)   stages on those bits

@@ -65,7 +65,8 @@ __device__ __forceinline__ uint32_t plant_hi(uint32_t X)
 // 0 <= a < PLANT_LIMIT  ->  (a * w) mod q, canonical.
 template <bool UNIFORM_W = true>
 __device__ __forceinline__ uint32_t plant(uint32_t a, uint32_t W) { return plant_hi(plant_lo<UNIFORM_W>(a, W)); }
-// a * b < 2^32  ->  -(a * b) * 2^-32 mod q, canonical (one factor carries -2^32 beforehand, or the constant is folded elsewhere).
+// a * b < 2^32  ->  -(a * b) * 2^-32 mod q, canonical. One factor carries a power of two beforehand: -2^32 (W_NEG_R) where
+// the product itself is wanted (polymul), +2^32 (W_POS_R, prepared keys) where its negative is (the verify kernel adds it to c).
 __device__ __forceinline__ uint32_t plant2(uint32_t a, uint32_t b) { return plant_hi(plant_lo<true>(a * b, QINV32)); }
 
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
