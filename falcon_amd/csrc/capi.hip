@@ -263,6 +263,8 @@ struct Tables {
   std::vector<Tw> fwdC;  // the same in the phase-C layout [lane][TWC], verify_kernel.hpp
   std::vector<Tw> inv;   // inverse (decimation in time): entry 2^b + j = omega^-(N/2^(b+1) * j), omega = zeta^2
   std::vector<Tw> isc;   // inverse scaling: entry p = zeta^-p / N (ntt.hpp:25-29 folded in)
+  std::vector<Tw> isc_pos;  // the same times 2^32: the packed-key verify kernel, whose pointwise product is -x*y*2^-32 (zq.hpp plant2_wide)
+  std::vector<Tw> isc_neg;  // the same times -2^32: polymul_kernel, same product, wanted with the other sign
   NttConsts nc;
 };
 Tables make_tables(int logn)
@@ -276,7 +278,14 @@ Tables make_tables(int logn)
   for (int b = 0; b < logn; b++)
     for (uint32_t j = 0; j < (1u << b); j++) t.inv[(1u << b) + j] = plant_const(powmod(oinv, (n >> (b + 1)) * j));
   t.isc.resize(n);
-  for (uint32_t p = 0; p < n; p++) t.isc[p] = plant_const(powmod(zinv, p) * ninv % Q);
+  t.isc_pos.resize(n);
+  t.isc_neg.resize(n);
+  for (uint32_t p = 0; p < n; p++) {
+    const uint32_t sc = powmod(zinv, p) * ninv % Q;
+    t.isc[p] = plant_const(sc);
+    t.isc_pos[p] = plant_const((uint32_t)((uint64_t)sc * POS_R % Q));
+    t.isc_neg[p] = plant_const((uint32_t)((uint64_t)sc * NEG_R % Q));
+  }
   for (int k = 0; k < 16; k++) t.nc.twA[k] = t.fwd[k];
   for (int k = 0; k < 8; k++) t.nc.itwA[k] = t.inv[k];
   // phase C: registers hold index bits [0, LB); the stage on bit lb uses, for lane L, the entries
@@ -461,6 +470,8 @@ struct fa_ctx {
   Tw* d_itw[2] = { nullptr, nullptr };
   Tw* d_twc[2] = { nullptr, nullptr };
   Tw* d_isc[2] = { nullptr, nullptr };
+  Tw* d_isc_pos[2] = { nullptr, nullptr };
+  Tw* d_isc_neg[2] = { nullptr, nullptr };
   NttConsts nc[2];
   uint32_t chunk = 1u << 20;
   uint32_t hash_blocks[2] = { 9, 17 };
@@ -803,7 +814,7 @@ int run_pass(fa_ctx* ctx, const Workspace& ws, hipStream_t s, uint32_t slots, co
   A.tw = ctx->d_tw[T];
   A.itw = ctx->d_itw[T];
   A.twc = ctx->d_twc[T];
-  A.isc = ctx->d_isc[T];
+  A.isc = B.keys.prepared ? ctx->d_isc[T] : ctx->d_isc_pos[T];  // the packed-key product lacks a factor 2^32 (verify_items)
   A.nc = ctx->nc[T];
   A.count = slots;
   A.dcount = dcount;
@@ -1035,7 +1046,7 @@ int polymul_dev(fa_ctx* ctx, size_t count, const uint16_t* a, const uint16_t* b,
     const size_t o = p0 << LOGN;
     const int rc = timed(ctx, s, 3, [&] {
       hipLaunchKernelGGL(polymul_kernel<LOGN>, dim3(grid), dim3(VERIFY_WG), 0, s, a + o, b + o, c + o, n, ctx->d_tw[T],
-                         ctx->d_itw[T], ctx->d_twc[T], ctx->d_isc[T], ctx->nc[T]);
+                         ctx->d_itw[T], ctx->d_twc[T], ctx->d_isc_neg[T], ctx->nc[T]);  // its product lacks a factor -2^32
     });
     if (rc) return rc;
   }
@@ -1208,6 +1219,10 @@ int fa_ctx_create(int device, fa_ctx** out)
     if (!rc) rc = (int)hipMalloc((void**)&ctx->d_isc[t], bytes);
     if (!rc) rc = (int)hipMemcpy(ctx->d_twc[t], tb.fwdC.data(), cbytes, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(ctx->d_isc[t], tb.isc.data(), bytes, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_isc_pos[t], bytes);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_isc_pos[t], tb.isc_pos.data(), bytes, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMalloc((void**)&ctx->d_isc_neg[t], bytes);
+    if (!rc) rc = (int)hipMemcpy(ctx->d_isc_neg[t], tb.isc_neg.data(), bytes, hipMemcpyHostToDevice);
   } catch (...) {  // std::bad_alloc while building the tables
     rc = FA_E_INTERNAL;
   }
@@ -1246,6 +1261,8 @@ void fa_ctx_destroy(fa_ctx* ctx)
     if (ctx->d_itw[t]) (void)hipFree(ctx->d_itw[t]);
     if (ctx->d_twc[t]) (void)hipFree(ctx->d_twc[t]);
     if (ctx->d_isc[t]) (void)hipFree(ctx->d_isc[t]);
+    if (ctx->d_isc_pos[t]) (void)hipFree(ctx->d_isc_pos[t]);
+    if (ctx->d_isc_neg[t]) (void)hipFree(ctx->d_isc_neg[t]);
   }
   if (ctx->h_word) (void)hipHostFree(ctx->h_word);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);

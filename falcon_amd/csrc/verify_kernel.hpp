@@ -25,7 +25,8 @@
 // Values are unsigned lazy residues below 2^32/q (zq.hpp). A butterfly widens the range by q on either side, so
 // the first stage of a transform adds BIAS = logn*q to its sums' inputs once; nothing is reduced in between:
 //   forward: inputs < 2^16            ->  outputs in [0, 2^16 + 2 logn q) < 311,316
-//   inverse: inputs <= q              ->  before the final scaling in [0, (2 logn + 1) q) <= 258,069;  after it < q
+//   inverse: inputs in [-64, q)       ->  before the final scaling in (0, (2 logn + 2) q + 128) <= 270,486;  after it < q
+//            (its bias is (logn + 1) q: the pointwise product of the packed-key path may be negative by its high word)
 // (the verify kernel itself leaves the inverse transform before that scaling: its epilogue does scaling, the addition
 // of c and the centring's reduction in ONE Plantard product, see verify_items)
 //
@@ -65,11 +66,17 @@ struct Geo {
   static constexpr int XBUF = N + 64;    // dwords of the padded transpose buffer
   static constexpr uint32_t BETA2 = LOGN == 9 ? 34034726u : 70265242u;  // falcon.hpp:245
   static constexpr uint32_t BIAS = (uint32_t)LOGN * Q;  // added once per transform: keeps every difference non-negative
+  // The inverse transform's inputs may be negative by a few units (plant2_wide, zq.hpp: down to -(product >> 32)): one q more.
+  static constexpr uint32_t BIAS_INV = BIAS + Q;
+  static constexpr uint32_t INV_IN_MIN = 64;  // inputs of the inverse transform lie in [-INV_IN_MIN, q)
   static constexpr int TWB = N >> PB;    // phase-B forward twiddle indices are < N >> PB
   static constexpr int TWC = LOGN == 9 ? 7 : 13;  // per-lane phase-C entries (odd stride; 7 resp. 12 used)
   static constexpr int PKDW = ((PKLEN + 6) / 4 + 63) / 64;  // aligned dwords per lane covering a key row (any alignment)
   static constexpr int MAXHW = LOGN == 9 ? 5 : 10;    // prefetched dwords of squeezed blocks per lane (9 / 17 blocks)
   static_assert(65535u + 2u * BIAS < PLANT_LIMIT, "forward transform of any u16 input stays below 2^32/q");
+  static_assert((2u * LOGN + 2u) * Q + 2u * INV_IN_MIN < PLANT_LIMIT, "inverse transform stays below 2^32/q");
+  static_assert(BIAS_INV > Q + INV_IN_MIN + ((uint32_t)LOGN - 1u) * (Q - 1u), "and above zero: the first stage leaves >= BIAS_INV - q - INV_IN_MIN, every later one takes at most q - 1");
+  static_assert(((65535ull + 2ull * BIAS) * (16383ull + 2ull * BIAS) >> 32) < INV_IN_MIN, "high word of a product of two forward outputs");
 };
 
 // offset of the first phase-C table entry of the stage on register bit lb (stages run lb = PB-1 .. 0,
@@ -212,7 +219,7 @@ __device__ __forceinline__ void bfly_stages(uint32_t (&x)[Geo<LOGN>::R], const T
     if (first) {
 #pragma unroll
       for (int m = 0; m < R; m++)
-        if (!(m & (1 << lb))) x[m] += Geo<LOGN>::BIAS;
+        if (!(m & (1 << lb))) x[m] += FORWARD ? Geo<LOGN>::BIAS : Geo<LOGN>::BIAS_INV;
     }
 #pragma unroll
     for (int m = 0, k = 0; m < R; m++) {
@@ -330,7 +337,7 @@ __device__ __forceinline__ void ntt_forward2(uint32_t (&x)[Geo<LOGN>::R], uint32
   bfly_stages<LOGN, true, G::PB, G::PB - 1, G::PB - 1, TW_PHASE_C, false>(y, T.fC, lane);
 }
 
-// x: <= q, phase-C layout (bit-reversed order)  ->  coefficients in phase-A layout (natural order), canonical,
+// x: in [-64, q) (as u32, wrapping), phase-C layout (bit-reversed order)  ->  coefficients in phase-A layout (natural order), canonical,
 // the 1/N of ntt.hpp:193-199 included in the final scaling. SCALE = false leaves the final scaling to the caller:
 // x[m] is then lazy (below (2 logn + 1) q) and still to be multiplied by T.sc[m << 6] (the verify kernel's epilogue
 // does that inside the reduction it needs anyway).
@@ -738,10 +745,11 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         FA_MARK("ntt_x");
         ntt_forward<LOGN>(x, T, buf, lane);
         FA_MARK("pointwise");
+        // polynomial.hpp:99-110, as -x*y*2^-32 from BOTH lazy factors in four instructions (zq.hpp plant2_wide: one
+        // v_mad_u64_u32 for the whole product, the Plantard reduction of its low word, minus its high word). The 2^32
+        // that is missing sits in this path's scaling table (A.isc = zeta^-p / n * 2^32, capi.hip make_tables).
 #pragma unroll
-        for (int m = 0; m < R; m++) x[m] = plant(x[m], W_POS_R);  // canonical, times 2^32
-#pragma unroll
-        for (int m = 0; m < R; m++) y[m] = plant2(x[m], y[m]);    // MINUS the product of polynomial.hpp:99-110; y < 16384 + 2 logn q
+        for (int m = 0; m < R; m++) y[m] = plant2_wide(x[m], y[m]);
       }
     }
     // x[] is dead: the next item's s2, into the same registers. One place for every path (an item that ran no transform
@@ -759,33 +767,45 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       // (verification.hpp:59-68: values >= half = 6144 go negative; the specification's centring has half = 6145), so
       // v + (q - half) is the canonical residue of u = craw + (q - half) + sc*y -- and that is ONE Plantard reduction:
       // the low products are linear, low(y * W_sc) + low(u0 * W_one) is the low product of the sum, and the high product
-      // by q reduces it (zq.hpp; exact because y * q + u0 * 1337 < 258,069 q + 79,878 * 1337 < 2^32). Per coefficient:
-      // low product, add, multiply-add, high product, subtract, multiply-add -- no comparison, no select, and the
-      // inverse transform's final scaling costs nothing of its own.
+      // by q reduces it (zq.hpp; exact because y * q + u0 * 1337 < 270,486 q + 79,878 * 1337 < 2^32). Both products are
+      // v_mad_u64_u32 (zq.hpp mad64), whose 64-bit addend takes the constants along for nothing: the first adds
+      // (q - half) * W_one to the low word, the second subtracts (q - half) from the high word. Per coefficient: product
+      // (+ constant), multiply-add of c, product (- constant), multiply-add of the square -- four instructions, no
+      // comparison, no select, and the inverse transform's final scaling costs nothing of its own.
       FA_MARK("epilogue");
       uint32_t acc = 0;
       const uint32_t shift = Q - A.half;
-      static_assert((2ull * LOGN + 1ull) * Q * (Q - 1ull) + (61444ull + Q) * NEG_R < (1ull << 32), "fused scaling and reduction");
+      static_assert(((2ull * LOGN + 2ull) * Q + 2ull * G::INV_IN_MIN) * (Q - 1ull) + (61444ull + Q) * NEG_R < (1ull << 32), "fused scaling and reduction");
+      const uint64_t add_lo = (uint64_t)(shift * W_ONE);         // low word: + (q - half) * W_one (mod 2^32)
+      const uint64_t add_hi = (uint64_t)(0u - shift) << 32;      // high word: - (q - half)      (both wave-uniform: scalar pairs)
+      // The Falcon-512 prepared-key variant keeps the two-instruction forms (low product + add, high product + subtract):
+      // the register pairs of the 64-bit results take it from 80 to 82 registers, i.e. from six waves per SIMD to five,
+      // and it loses more by that (+4 % cycles, measured) than the four instructions per coefficient gain.
+      constexpr bool WIDE = !(PREPARED && LOGN == 9);
+      uint32_t qv = Q;                                           // q as a vector operand: the scalar one is the addend
+      if constexpr (WIDE) asm volatile("" : "+v"(qv));
+      constexpr int EG = WIDE ? 4 : 8;
 #pragma unroll
-      for (int m0 = 0; m0 < R; m0 += 8) {  // eight at a time: Falcon-1024's sixteen would cost its fourth wave per SIMD
-        uint32_t craw[8], w[8];
+      for (int m0 = 0; m0 < R; m0 += EG) {  // a few at a time: the 64-bit results are register pairs, and six waves per SIMD end at 80 registers
+        uint32_t craw[EG], w[EG];
 #pragma unroll
-        for (int k = 0; k < 8; k++) craw[k] = cbuf[idxA<LOGN>(lane, m0 + k)];  // < 61445
+        for (int k = 0; k < EG; k++) craw[k] = cbuf[idxA<LOGN>(lane, m0 + k)];  // < 61445
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = plant_lo<false>(y[m0 + k], T.sc[(m0 + k) << 6]);
+        for (int k = 0; k < EG; k++)
+          w[k] = WIDE ? (uint32_t)mad64(y[m0 + k], T.sc[(m0 + k) << 6], add_lo) : plant_lo<false>(y[m0 + k], T.sc[(m0 + k) << 6]);
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] += __umul24(craw[k] + shift, W_ONE);
+        for (int k = 0; k < EG; k++) w[k] += __umul24(WIDE ? craw[k] : craw[k] + shift, W_ONE);
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = plant_hi(w[k]);                     // v + (q - half), in [0, q)
+        for (int k = 0; k < EG; k++) w[k] = WIDE ? (uint32_t)(mad64(w[k], qv, add_hi) >> 32) : plant_hi(w[k]) - shift;  // v = s1 centred, as i32
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < EG; k++) {
           const int m = m0 + k;
           const uint32_t i = idxA<LOGN>(lane, m);
-          const int32_t v = (int32_t)w[k] - (int32_t)shift;                    // centred s1
+          const int32_t v = (int32_t)w[k];
           // acc += v * v (|v| <= 6145), stated as the one instruction it is: left to itself hipcc multiplies the eight
           // squares apart and adds them up in threes, eleven instructions instead of eight
           asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(acc) : "v"(v));
@@ -1035,7 +1055,7 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
                                                             uint16_t* __restrict__ c, uint32_t count,
                                                             const Tw* __restrict__ tw, const Tw* __restrict__ itw,
                                                             const Tw* __restrict__ twc, const Tw* __restrict__ isc,
-                                                            const NttConsts nc)
+                                                            const NttConsts nc)  // isc: zeta^-p / n * (-2^32), see below
 {
   using G = Geo<LOGN>;
   constexpr int N = G::N, R = G::R;
@@ -1074,10 +1094,9 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
       y[m] = bv[m];
     }
     ntt_forward2<LOGN>(x, y, T, buf, s_buf2[wave], lane);
+    static_assert(((65535ull + 2ull * G::BIAS) * (65535ull + 2ull * G::BIAS) >> 32) < G::INV_IN_MIN, "high word of the product");
 #pragma unroll
-    for (int m = 0; m < R; m++) x[m] = plant(x[m], W_NEG_R);  // canonical, times -2^32
-#pragma unroll
-    for (int m = 0; m < R; m++) x[m] = plant2(x[m], y[m]);    // polynomial.hpp:99-110; y < 2^16 + 2 logn q
+    for (int m = 0; m < R; m++) x[m] = plant2_wide(x[m], y[m]);  // polynomial.hpp:99-110 as -x*y*2^-32; `isc` carries the -2^32
     ntt_inverse<LOGN>(x, T, buf, lane);
 #pragma unroll
     for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)x[m];
