@@ -48,12 +48,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # signature decoding 10 per coefficient. By construction these are <= what the kernels issue, so achieved / peak <= 1.
 # REF_OPS is SURVEY.md 8(d)'s model of the REFERENCE's work (11 per butterfly, 4 transforms), reported beside it only.
 # Round 3: a butterfly is 4 (two-instruction Plantard product, add, subtract); the inverse transform's first stage
-# multiplies nothing (2 per butterfly); its final scaling is part of the epilogue's one reduction (6 per coefficient:
-# low product, add, multiply-add, high product, subtract, multiply-add); pointwise 5 (reduction + product), key unpack 2,
-# 3 per draw of the rejection sampling.
+# multiplies nothing (2 per butterfly); its final scaling is part of the epilogue's one reduction (4 per coefficient:
+# 64-bit multiply-add, multiply-add, 64-bit multiply-add, multiply-add); pointwise 4 (64-bit product, low product, high
+# product, subtract), key unpack 2, 3 per draw of the rejection sampling.
 def _verify_ops(n, logn, draws):
     bf = n // 2 * logn                     # butterflies per transform
-    return 2 * bf * 4 + ((bf - n // 2) * 4 + n // 2 * 2) + n * 5 + n * 2 + n * 6 + draws * 3
+    return 2 * bf * 4 + ((bf - n // 2) * 4 + n // 2 * 2) + n * 4 + n * 2 + n * 4 + draws * 3
 
 
 ALG_OPS = {
@@ -68,7 +68,7 @@ ALG_OPS_R02_VERIFY = {9: 3 * 2304 * 5 + 512 * 5 + 512 * 2 + 512 * 6 + 612 * 3,  
                       10: 3 * 5120 * 5 + 1024 * 5 + 1024 * 2 + 1024 * 6 + 1224 * 3}   # so that the rounds' fractions can be compared
 REF_OPS_512 = {"hash_kernel": 8.593 * 7440, "verify_kernel": 9216 * 11 + 1024 * 5 + 546 * 4 + 512 * 3 + 512 * 3,
                "decode_kernel": 512 * 10}
-POLYMUL_OPS_512 = 2 * 2304 * 4 + (2048 * 4 + 256 * 2 + 512 * 2) + 512 * 5   # transforms, pointwise (reduction + product)
+POLYMUL_OPS_512 = 2 * 2304 * 4 + (2048 * 4 + 256 * 2 + 512 * 2) + 512 * 4   # transforms (final scaling 2), pointwise (4)
 BYTES = {9: 897 + 666 + 32 + 1, 10: 1793 + 1280 + 32 + 1}   # compulsory HBM bytes per verify
 PEAK_VALU_TIOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (full-rate instructions)
 PEAK_HBM_GBS = 8000.0

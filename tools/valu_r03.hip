@@ -46,6 +46,28 @@
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s;                         \
   }
 
+// v_mad_u64_u32: the whole 32 x 32 -> 64 product plus a 64-bit addend; the chain runs through the low word of the result.
+// ADDEND: "v" = a vector register pair, "s" = a scalar pair (wave-uniform addend, as the verify kernel's epilogue has it).
+#define DEFKERNEL_MAD64(NAME, ADDEND)                                                 \
+  __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed)           \
+  {                                                                                   \
+    uint64_t x[CHAINS];                                                               \
+    uint32_t a = seed + threadIdx.x, b = seed * 3u + 7u;                              \
+    uint64_t cs = ((uint64_t)seed << 32) | 12345u;                                    \
+    _Pragma("unroll") for (int c = 0; c < CHAINS; c++) x[c] = a + c;                  \
+    for (int i = 0; i < ITERS; i++) {                                                 \
+      _Pragma("unroll") for (int c = 0; c < CHAINS; c++) {                            \
+        const uint32_t lo = (uint32_t)x[c];                                           \
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(x[c]) : "v"(lo), "v"(b), ADDEND(cs) : "vcc"); \
+      }                                                                               \
+    }                                                                                 \
+    uint64_t s = 0;                                                                   \
+    _Pragma("unroll") for (int c = 0; c < CHAINS; c++) s ^= x[c];                     \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);   \
+  }
+DEFKERNEL_MAD64(k_mad64_v, "v")
+DEFKERNEL_MAD64(k_mad64_s, "s")
+
 DEFKERNEL(k_add, "v_add_u32 %0, %0, %1")
 DEFKERNEL(k_sub, "v_sub_u32 %0, %0, %1")
 DEFKERNEL(k_mul_u24, "v_mul_u32_u24 %0, %0, %1")
@@ -200,7 +222,8 @@ int main()
                    {"v_add_u32_sdwa src1:WORD_1", k_add_sdwa}, {"v_sub_u32_sdwa src1:WORD_1", k_sub_sdwa}, {"v_perm_b32", k_perm},
                    {"v_bfi_b32", k_bfi}, {"v_lshl_add_u32", k_lshl_add}, {"v_add3_u32", k_add3}, {"v_fma_f32", k_fma_f32},
                    {"v_mul_f32", k_mul_f32}, {"v_pk_fma_f32 (2 per lane)", k_pk_fma_f32}, {"v_pk_mul_f32 (2 per lane)", k_pk_mul_f32},
-                   {"v_pk_add_f32 (2 per lane)", k_pk_add_f32} };
+                   {"v_pk_add_f32 (2 per lane)", k_pk_add_f32},
+                   {"v_mad_u64_u32 (64-bit result, vector addend)", k_mad64_v}, {"v_mad_u64_u32 (64-bit result, scalar addend)", k_mad64_s} };
   hipDeviceProp_t prop;
   (void)hipGetDeviceProperties(&prop, 0);
   const double clk = prop.clockRate * 1e3;
