@@ -140,7 +140,7 @@ __device__ __forceinline__ void hash_body(uint32_t block, const Rows& sig,
                                           const uint32_t* __restrict__ idx, uint32_t count, const uint32_t* __restrict__ dcount,
                                           uint32_t nblk, uint64_t* __restrict__ hraw)
 {
-  __shared__ uint64_t stage[WG / 64][64 * 17];
+  __shared__ uint64_t stage[WG / 64][64 * 9];  // one pass of a block: 9 words per lane (the second pass uses 8 of them)
   const uint32_t slot = block * WG + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (dcount) count = min(count, *dcount);  // device-side number of slots (retry pass, mixed batches)
@@ -194,46 +194,53 @@ __device__ __forceinline__ void hash_body(uint32_t block, const Rows& sig,
   }
 
   // --- squeeze nblk blocks (hashing.hpp:36-39); wave-uniform trip count ---
-  // A block leaves the wave through LDS: lane L writes its 17 words (as 34 dwords, ds_write2_b32 takes the halves from
-  // wherever they are: no register pairs to assemble), then the 64 x 17 words go out THREE ROWS per store -- lane L < 51
-  // holds word L % 17 of row 3 t + L / 17, i.e. LDS words 51 t + L, and the three 136-byte pieces of a store lie one row
-  // stride apart. The point of the three: a lane's part of the address ((L / 17) * row stride + L % 17) does not depend on
-  // t or the block, so it is computed once, and a store's address is one vector add to a scalar base. (17 stores of 64 consecutive words
-  // need e / 17 and e % 17 per lane and store: 170 vector instructions per block, 34 of them 64-bit multiply-adds.)
+  // A block leaves the wave through LDS, in two passes (words 0..8, then 9..16: half the staging buffer, so that the LDS
+  // does not cap the kernel at four waves per SIMD): lane L writes its words of the pass (as dwords, ds_write2_b32 takes the
+  // halves from wherever they are: no register pairs to assemble), then the 64 rows go out SEVEN (EIGHT) rows per store --
+  // lane L holds word L % nw of row RP t + L / nw, i.e. LDS word (RP t + L / nw) * 9 + L % nw, and the pieces of a store lie
+  // one row stride apart. The point of whole rows per store: a lane's part of the address ((L / nw) * row stride + L % nw)
+  // does not depend on t or the block, so it is computed once, and a store's address is one vector add to a scalar base.
+  // (17 stores of 64 consecutive words need e / 17 and e % 17 per lane and store.)
   uint32_t* st32 = (uint32_t*)stage[wave];
   const uint64_t* st = stage[wave];
   const uint32_t slot0 = block * WG + wave * 64u;  // first slot of this wave
   const uint32_t row_words = nblk * 17u;
-  const uint32_t r0 = lane / 17u, w0 = lane - r0 * 17u;
-  const uint32_t lane_words = r0 * row_words + w0;  // < 4 * 17 * nblk
   const bool full = slot0 + 64u <= count;           // wave-uniform: every row of this wave is a slot
   uint64_t* wave_rows = hraw + (size_t)slot0 * row_words;
   for (uint32_t b = 0; b < nblk; b++) {
     keccak_f1600(a);
-#pragma unroll
-    for (int w = 0; w < 17; w++) {
-      st32[(lane * 17u + w) * 2u] = a[w].lo;
-      st32[(lane * 17u + w) * 2u + 1u] = a[w].hi;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint64_t* blk_rows = wave_rows + (size_t)b * 17u;
-    auto store_rows = [&](auto checked) {  // a full wave (all but the batch's last) tests no row against the count
+    auto pass = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr int W0 = FIRST ? 0 : 9, NW = FIRST ? 9 : 8, RP = 64 / NW, NST = (64 + RP - 1) / RP;
 #pragma unroll
-      for (int t = 0; t < 22; t++) {
-        const uint32_t row = 3u * t + r0;
-        bool mine = lane < 51u && (t < 21 || r0 == 0u);
-        if (decltype(checked)::value) mine = mine && slot0 + row < count;
-        uint64_t* rows_t = blk_rows + (size_t)(3u * t) * row_words;  // wave-uniform
-        if (mine) rows_t[lane_words] = st[51u * t + lane];
+      for (int w = 0; w < NW; w++) {
+        st32[(lane * 9u + w) * 2u] = a[W0 + w].lo;
+        st32[(lane * 9u + w) * 2u + 1u] = a[W0 + w].hi;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t r0 = lane / (uint32_t)NW, w0 = lane - r0 * (uint32_t)NW;
+      const uint32_t lane_words = r0 * row_words + w0 + (uint32_t)W0;
+      auto store_rows = [&](auto checked) {  // a full wave (all but the batch's last) tests no row against the count
+#pragma unroll
+        for (int t = 0; t < NST; t++) {
+          const uint32_t row = (uint32_t)(RP * t) + r0;
+          bool mine = r0 < (uint32_t)RP && (RP * (t + 1) <= 64 || row < 64u);
+          if (decltype(checked)::value) mine = mine && slot0 + row < count;
+          uint64_t* rows_t = blk_rows + (size_t)(RP * t) * row_words;  // wave-uniform
+          if (mine) rows_t[lane_words] = st[(uint32_t)(RP * t * 9) + r0 * 9u + w0];
+        }
+      };
+      if (full) store_rows(std::false_type{});
+      else store_rows(std::true_type{});
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    if (full) store_rows(std::false_type{});
-    else store_rows(std::true_type{});
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    pass(std::true_type{});
+    pass(std::false_type{});
   }
 }
 
