@@ -820,9 +820,18 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         }
       }
       FA_MARK("norm");
-      // per-lane sums are < 2^30 but the wave total needs 36 bits: reduce the low 24 bits and the rest apart
-      unsigned long long total = (unsigned long long)wave_sum_u32(acc & 0xffffffu) +
-                                 ((unsigned long long)wave_sum_u32(acc >> 24) << 24);
+      // per-lane sums are < 2^30 but the wave total needs 36 bits: reduce the low 24 bits and the rest apart.
+      // Falcon-512 under the exact policy, no debug outputs: ONE reduction of min(acc, 2^26 - 1). beta^2 < 2^26 - 1, so a
+      // lane that is clamped decides the item by itself (the clamped total is still above beta^2, as the true one is),
+      // sixty-four clamped values fit 32 bits, and with no lane clamped the total is exact.
+      unsigned long long total;
+      constexpr uint32_t CLAMP = (1u << 26) - 1u;
+      if (!DEBUG && LOGN == 9 && !A.wrap32) {
+        static_assert(LOGN != 9 || G::BETA2 < CLAMP, "a clamped lane alone exceeds beta^2");
+        total = (unsigned long long)wave_sum_u32(min(acc, CLAMP));
+      } else {
+        total = (unsigned long long)wave_sum_u32(acc & 0xffffffu) + ((unsigned long long)wave_sum_u32(acc >> 24) << 24);
+      }
       total += sqn;
       const uint32_t wrapped = (uint32_t)total;
       const bool ok = A.wrap32 ? ((int32_t)wrapped <= (int32_t)G::BETA2) : (total <= (unsigned long long)G::BETA2);
