@@ -512,6 +512,7 @@ struct ItemRegs {
   uint32_t pkw[Geo<LOGN>::PKDW];   // key row, aligned dword t*64+lane          (packed keys)
   uint32_t hk[Geo<LOGN>::R / 2];   // prepared key, coefficients lane*R .. lane*R+R-1, two per dword
   uint32_t sqn, st, item, pal;
+  uint32_t key;                    // prepared keys: the item's key index (wave-uniform)
 };
 
 template <int LOGN, bool PREPARED, bool GENERAL>
@@ -521,15 +522,9 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   slot = __builtin_amdgcn_readfirstlane(slot);  // wave-uniform: row bases become scalar, lanes add 32-bit offsets
   r.item = A.idx ? A.idx[slot] : slot;
   r.item = __builtin_amdgcn_readfirstlane(r.item);
-  uint32_t key = 0;
   if constexpr (PREPARED) {  // the key's index, before the bulk loads: a load that must be waited for in the middle of
-    key = A.key_idx ? A.key_idx[r.item] : A.item_base + r.item;  // them makes every load before it a load waited for
-    key = __builtin_amdgcn_readfirstlane(key);
-  }
-  if constexpr (PREPARED) {
-    const uint32_t* krow = (const uint32_t*)(A.prepared + (size_t)key * G::N);
-#pragma unroll
-    for (int j = 0; j < G::R / 2; j++) r.hk[j] = krow[lane * (G::R / 2) + j];
+    const uint32_t key = A.key_idx ? A.key_idx[r.item] : A.item_base + r.item;  // them makes every load before it a load waited for
+    r.key = __builtin_amdgcn_readfirstlane(key);  // (the key row itself is requested later, with s2: prefetch_key)
   }
   const uint32_t* hrow = (const uint32_t*)(A.hraw + (size_t)slot * A.nblk * 17u);
   const uint32_t ndw = A.nblk * 34u;
@@ -539,7 +534,7 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
     r.hw[t] = d < ndw ? hrow[d] : 0xffffffffu;  // 0xffff draws are always rejected
   }
   if constexpr (PREPARED) {
-    r.pal = 0u;  // (the key row was requested first, above)
+    r.pal = 0u;
   } else {
     const uint8_t* pkrow = GENERAL ? A.pk.at(r.item) : A.pk.base + (size_t)r.item * G::PKLEN;
     r.pal = (uint32_t)((uintptr_t)pkrow & 3u);
@@ -553,6 +548,18 @@ __device__ __forceinline__ void prefetch_item(const VerifyArgs<LOGN>& A, uint32_
   }
   r.sqn = A.sqn[slot];
   r.st = A.st2[slot];
+}
+
+// The prepared key of an item: like s2 it is requested when its registers are free, after the pointwise product that is
+// their last use -- the product reads cur.hk itself, no copy -- and arrives behind the inverse transform.
+template <int LOGN>
+__device__ __forceinline__ void prefetch_key(const uint16_t* __restrict__ prepared, uint32_t key, uint32_t lane,
+                                             uint32_t (&hk)[Geo<LOGN>::R / 2])
+{
+  using G = Geo<LOGN>;
+  const uint32_t* krow = (const uint32_t*)(prepared + (size_t)__builtin_amdgcn_readfirstlane(key) * G::N);
+#pragma unroll
+  for (int j = 0; j < G::R / 2; j++) hk[j] = krow[lane * (G::R / 2) + j];
 }
 
 // The s2 part of an item's loads, apart from the rest: its registers are the ones the item's first transform works in,
@@ -612,6 +619,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
   if (slot >= count) return;
   ItemRegs<LOGN> cur;
   prefetch_item<LOGN, PREPARED, GENERAL>(A, slot, lane, cur);
+  if constexpr (PREPARED) prefetch_key<LOGN>(A.prepared, cur.key, lane, cur.hk);
   prefetch_s2<LOGN>(A.s2, slot, lane, cur.s2v);
   s2_arrived<LOGN>(cur.s2v);  // once per wave: the first item's s2 is waited for here
 
@@ -689,16 +697,13 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
     const bool run = status == ST_OK && !done;
     uint32_t (&x)[R] = cur.s2v;  // the first transform works in the registers the loads filled
     uint32_t y[R];
-    uint32_t hk[PREPARED ? R / 2 : 1], s2keep[DEBUG ? R : 1];
+    uint32_t s2keep[DEBUG ? R : 1];
     if (run) {
       if constexpr (DEBUG) {
 #pragma unroll
         for (int m = 0; m < R; m++) s2keep[m] = cur.s2v[m];
       }
-      if constexpr (PREPARED) {
-#pragma unroll
-        for (int j = 0; j < R / 2; j++) hk[j] = cur.hk[j];
-      } else {
+      if constexpr (!PREPARED) {
         // ---- public key: 14-bit little-endian fields after the header byte (decoding.hpp:34-45), taken
         //      lazily (equivalent to the reference's raw values). The row was loaded
         //      as contiguous dwords; it goes through LDS so each lane can pick its own fields. ----
@@ -734,7 +739,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         ntt_forward<LOGN>(x, T, buf, lane);
 #pragma unroll
         for (int m = 0; m < R; m++) {  // 2^32 NTT(h), canonical, already in this lane's phase-C positions
-          const uint32_t hv = (hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
+          const uint32_t hv = (cur.hk[m >> 1] >> (16 * (m & 1))) & 0xffffu;
           y[m] = plant2(x[m], hv);  // MINUS the product of polynomial.hpp:99-110; x < 2^16 + 2 logn q, hv < q: below 2^32
         }
       } else {
@@ -757,6 +762,7 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
     // would be what the registers hold on the other path) and bring a copy back; the last iteration loads its own
     // row once more instead. The loads arrive behind the inverse transform and the epilogue; s2_arrived() at the end
     // of the iteration waits for them.
+    if constexpr (PREPARED) prefetch_key<LOGN>(A.prepared, cur.key, lane, cur.hk);  // cur.key: the next item's if there is one
     prefetch_s2<LOGN>(A.s2, more ? nslot : slot, lane, cur.s2v);
     if (run) {
       FA_MARK("intt");
@@ -778,13 +784,9 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
       static_assert(((2ull * LOGN + 2ull) * Q + 2ull * G::INV_IN_MIN) * (Q - 1ull) + (61444ull + Q) * NEG_R < (1ull << 32), "fused scaling and reduction");
       const uint64_t add_lo = (uint64_t)(shift * W_ONE);         // low word: + (q - half) * W_one (mod 2^32)
       const uint64_t add_hi = (uint64_t)(0u - shift) << 32;      // high word: - (q - half)      (both wave-uniform: scalar pairs)
-      // The Falcon-512 prepared-key variant keeps the two-instruction forms (low product + add, high product + subtract):
-      // the register pairs of the 64-bit results take it from 80 to 82 registers, i.e. from six waves per SIMD to five,
-      // and it loses more by that (+4 % cycles, measured) than the four instructions per coefficient gain.
-      constexpr bool WIDE = !(PREPARED && LOGN == 9);
       uint32_t qv = Q;                                           // q as a vector operand: the scalar one is the addend
-      if constexpr (WIDE) asm volatile("" : "+v"(qv));
-      constexpr int EG = WIDE ? 4 : 8;
+      asm volatile("" : "+v"(qv));
+      constexpr int EG = 4;
 #pragma unroll
       for (int m0 = 0; m0 < R; m0 += EG) {  // a few at a time: the 64-bit results are register pairs, and six waves per SIMD end at 80 registers
         uint32_t craw[EG], w[EG];
@@ -792,14 +794,13 @@ __device__ __forceinline__ void verify_items(const VerifyArgs<LOGN>& A, const Tw
         for (int k = 0; k < EG; k++) craw[k] = cbuf[idxA<LOGN>(lane, m0 + k)];  // < 61445
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < EG; k++)
-          w[k] = WIDE ? (uint32_t)mad64(y[m0 + k], T.sc[(m0 + k) << 6], add_lo) : plant_lo<false>(y[m0 + k], T.sc[(m0 + k) << 6]);
+        for (int k = 0; k < EG; k++) w[k] = (uint32_t)mad64(y[m0 + k], T.sc[(m0 + k) << 6], add_lo);
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < EG; k++) w[k] += __umul24(WIDE ? craw[k] : craw[k] + shift, W_ONE);
+        for (int k = 0; k < EG; k++) w[k] += __umul24(craw[k], W_ONE);
         valu_fence();
 #pragma unroll
-        for (int k = 0; k < EG; k++) w[k] = WIDE ? (uint32_t)(mad64(w[k], qv, add_hi) >> 32) : plant_hi(w[k]) - shift;  // v = s1 centred, as i32
+        for (int k = 0; k < EG; k++) w[k] = (uint32_t)(mad64(w[k], qv, add_hi) >> 32);  // v = s1 centred, as i32
         valu_fence();
 #pragma unroll
         for (int k = 0; k < EG; k++) {
