@@ -1079,43 +1079,43 @@ __global__ __launch_bounds__(VERIFY_WG) void polymul_kernel(const uint16_t* __re
   const uint32_t nwaves = gridDim.x * VERIFY_WAVES;
   uint32_t p = blockIdx.x * VERIFY_WAVES + wave;
   if (p >= count) return;
-  uint32_t av[R], bv[R];
+  // One row of u16 coefficients into the phase-A layout (element 64 m + lane): scalar row base, one vector byte offset,
+  // the register index in the immediate offset. Written as instructions for the reasons prefetch_s2 gives; rows_arrived()
+  // is what makes the values usable (tools/check_asm_loads.py checks that nothing touches them before it).
+  auto load_row = [&](const uint16_t* base, uint32_t row, uint32_t (&v)[R]) {
+    const uint16_t* rb = base + (size_t)__builtin_amdgcn_readfirstlane(row) * N;  // wave-uniform, and known to be
+    const uint32_t off = lane * 2u;
 #pragma unroll
-  for (int m = 0; m < R; m++) {
-    av[m] = a[(size_t)p * N + idxA<LOGN>(lane, m)];
-    bv[m] = b[(size_t)p * N + idxA<LOGN>(lane, m)];
-  }
-  vmem_wait_all();  // as in verify_kernel: nothing outstanding at the loop header
+    for (int m = 0; m < R; m++)
+      asm volatile("global_load_ushort %0, %1, %2 offset:%3 ; FA_ASM_LOAD" : "=v"(v[m]) : "v"(off), "s"(rb), "n"(m * 128));
+  };
+  auto rows_arrived = [&](uint32_t (&u)[R], uint32_t (&v)[R]) {
+    asm volatile("s_waitcnt vmcnt(0) ; FA_ASM_LOAD_WAIT" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < R; m++) asm volatile("" : "+v"(u[m]), "+v"(v[m]));
+  };
+  // Two arrays and no copies: a's transform and the product live in x[], b's transform in y[]. y[] is dead after the
+  // pointwise product and takes the next b at once; x[] is dead after the stores of c and takes the next a then. That
+  // last request is waited for straight away -- the other five waves of the SIMD run meanwhile.
+  uint32_t x[R], y[R];  // inputs may be any u16 (the reference's ff_t ctor reduces, ff.hpp:69-76): lazy residues
+  load_row(a, p, x);
+  load_row(b, p, y);
+  rows_arrived(x, y);
   while (true) {
     const uint32_t np = p + nwaves;
     const bool more = np < count;
-    uint32_t an[R], bn[R];
-    if (more) {
-#pragma unroll
-      for (int m = 0; m < R; m++) {
-        an[m] = a[(size_t)np * N + idxA<LOGN>(lane, m)];
-        bn[m] = b[(size_t)np * N + idxA<LOGN>(lane, m)];
-      }
-    }
-    uint32_t x[R], y[R];
-#pragma unroll
-    for (int m = 0; m < R; m++) {
-      x[m] = av[m];  // inputs may be any u16 (the reference's ff_t ctor reduces, ff.hpp:69-76): lazy residues
-      y[m] = bv[m];
-    }
+    const uint32_t pn = more ? np : p;  // the last trip loads its own rows once more: no conditional load, no second path
     ntt_forward2<LOGN>(x, y, T, buf, s_buf2[wave], lane);
     static_assert(((65535ull + 2ull * G::BIAS) * (65535ull + 2ull * G::BIAS) >> 32) < G::INV_IN_MIN, "high word of the product");
 #pragma unroll
     for (int m = 0; m < R; m++) x[m] = plant2_wide(x[m], y[m]);  // polynomial.hpp:99-110 as -x*y*2^-32; `isc` carries the -2^32
+    load_row(b, pn, y);
     ntt_inverse<LOGN>(x, T, buf, lane);
 #pragma unroll
     for (int m = 0; m < R; m++) c[(size_t)p * N + idxA<LOGN>(lane, m)] = (uint16_t)x[m];
+    load_row(a, pn, x);
+    rows_arrived(x, y);
     if (!more) break;
-#pragma unroll
-    for (int m = 0; m < R; m++) {
-      av[m] = an[m];
-      bv[m] = bn[m];
-    }
     p = np;
   }
 }
